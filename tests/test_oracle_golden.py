@@ -1,0 +1,80 @@
+"""Pin the CPU oracle (oracle/) to the golden vectors captured from the imported reference.
+
+SURVEY.md §8c: the reference has no tests of its own for this path, so these fixtures
+(tools/gen_golden.py) are what "same results as the reference" means.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from adaptigraph_amd import configs
+from oracle import ag_oracle as ago
+
+TOL = 2e-5   # fp32 summation-order noise between torch-CPU sgemm and the oracle's k-ordered fma chains
+
+
+@pytest.mark.parametrize("name", golden_files("edges_"))
+def test_edges_exact(name):
+    g = load_golden(name)
+    n_rel, recv, send = ago.build_edges(g["pos"], g["radius"], g["mask"], g["tool_mask"], int(g["topk"]),
+                                        bool(g["connect_tools_all"]), str(g["variant"]), e_cap=g["recv"].shape[1] + 8)
+    assert np.array_equal(n_rel, g["n_rel"])
+    for b, n in enumerate(n_rel):
+        assert np.array_equal(recv[b, :n], g["recv"][b, :n]), f"sample {b} receivers"
+        assert np.array_equal(send[b, :n], g["send"][b, :n]), f"sample {b} senders"
+        assert np.all(np.diff(recv[b, :n].astype(np.int64) * g["pos"].shape[1] + send[b, :n]) > 0)  # CSR order
+
+
+@pytest.mark.parametrize("name", golden_files("fwd_"))
+def test_forward(name, weights):
+    g = load_golden(name)
+    w = dict(weights)
+    s = float(g["decoder_scale"])
+    if s != 1.0:
+        w["non_rigid_predictor.linear_2.weight"] = w["non_rigid_predictor.linear_2.weight"] * np.float32(s)
+        w["non_rigid_predictor.linear_2.bias"] = w["non_rigid_predictor.linear_2.bias"] * np.float32(s)
+    pos, mot = ago.forward(w, g["state"], g["attrs"], g["action"], g["p_instance"], g["phys"], g["n_rel"], g["recv"],
+                           g["send"])
+    scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
+    assert np.abs(mot - g["pred_motion"]).max() <= TOL * scale
+    assert np.abs(pos - g["pred_pos"]).max() <= TOL * scale
+    if s != 1.0:   # the clamp (model.py:309) must have been exercised
+        assert np.abs(g["pred_motion"]).max() > 100 and np.abs(pos - g["state"][:, -1, :pos.shape[1]]).max() <= 100.0
+
+
+@pytest.mark.parametrize("name", golden_files("decode_action"))
+def test_decode_action(name):
+    g = load_golden(name)
+    d, r = ago.decode_action(g["action"], float(g["push_length"]))
+    assert np.array_equal(r, g["repeat"])
+    assert np.abs(d - g["decoded"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", golden_files("dyn_"))
+def test_dynamics(name, weights):
+    g = load_golden(name)
+    task = configs.task_config(str(g["material"]))
+    seq, dec = ago.dynamics(weights, task, g["state"], g["action"])
+    assert np.abs(dec - g["action_seqs"]).max() <= 1e-6
+    assert np.abs(seq - g["state_seqs"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", golden_files("dynmask_"))
+def test_dynamics_masked(name, weights):
+    g = load_golden(name)
+    task = configs.task_config(str(g["material"]))
+    seq, dec = ago.dynamics_masked(weights, task, g["state_init"], g["state_mask"], g["action"])
+    assert np.abs(dec - g["action_seqs"]).max() <= 1e-6
+    assert np.abs(seq - g["state_seqs"]).max() <= 1e-4
+
+
+def test_top_k_tie_rule_is_lowest_index():
+    # duplicate points => exactly equal distances; the oracle's documented rule keeps the lower sender index
+    pos = np.zeros((1, 6, 3), np.float32)
+    pos[0, 1:5, 0] = 0.1           # four senders at identical distance from particle 0
+    pos[0, 5, 0] = 5.0
+    mask = np.ones((1, 6), bool)
+    tool = np.zeros((1, 6), bool)
+    n, recv, send = ago.build_edges(pos, 0.5, mask, tool, topk=3, connect_tools_all=False, variant="batch")
+    row0 = send[0, :n[0]][recv[0, :n[0]] == 0]
+    assert row0.tolist() == [0, 1, 2]

@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the imported reference (CPU, this container only).
+
+    python tools/gen_golden.py
+
+Every fixture holds inputs and the reference's outputs for one hot-path function
+(SURVEY.md §8a rows a5, a6, a7, a9, a10, a11).  Fixtures are data only; nothing from
+/root/reference is copied.  Weights are the reference module's own default init under
+torch.manual_seed(0) (no trained checkpoint exists offline).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+from ref_import import import_reference  # noqa: E402
+from adaptigraph_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF_CFG = "/root/reference/src/config"
+
+
+def load_cfg(material):
+    with open(f"{REF_CFG}/dynamics/{material}.yaml") as f:
+        dyn = yaml.safe_load(f)
+    with open(f"{REF_CFG}/planning/{material}.yaml") as f:
+        plan = yaml.safe_load(f)["task_config"]
+    return dyn, plan
+
+
+def build_model(R, material, seed=0):
+    dyn, _ = load_cfg(material)
+    torch.manual_seed(seed)
+    model = R.DynamicsPredictor(dyn["model_config"], dyn["material_config"], dyn["dataset_config"], "cpu")
+    model.eval()
+    return model
+
+
+def onehots_to_edges(Rr, Rs):
+    """(B, n_rel, N) one-hot pair -> per-sample count + padded index arrays (-1 pad)."""
+    B, E, _ = Rr.shape
+    valid = Rr.sum(-1) > 0
+    n = valid.sum(1).numpy().astype(np.int32)
+    recv = np.full((B, E), -1, np.int32)
+    send = np.full((B, E), -1, np.int32)
+    r = Rr.argmax(-1).numpy()
+    s = Rs.argmax(-1).numpy()
+    v = valid.numpy()
+    recv[v] = r[v]
+    send[v] = s[v]
+    return n, recv, send
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ------------------------------------------------------------------ edge-builder fixtures (rows a6, a7)
+def gen_edges(R):
+    cases = []
+    rng = np.random.default_rng(7)
+
+    def add(name, material, n_obj, batch, variant, radius=None, n_pad=0, topk=None, connect=None, **kw):
+        g = synth.make_graph_inputs(material, n_obj, batch, seed=len(cases) + 11, n_pad=n_pad, **kw)
+        m = synth.MATERIALS[material]
+        radius = m["radius"] if radius is None else radius
+        topk = m["topk"] if topk is None else topk
+        connect = m["connect_tools_all"] if connect is None else connect
+        pos = g["state"][:, -1]
+        if variant == "single":
+            outs = [R.construct_edges_from_states(t(pos[b]), float(radius), t(g["mask"][b]), t(g["tool_mask"][b]),
+                                                  topk=topk, connect_tools_all=connect) for b in range(batch)]
+            E = max(o[0].shape[0] for o in outs)
+            Rr = torch.zeros(batch, E, pos.shape[1])
+            Rs = torch.zeros(batch, E, pos.shape[1])
+            for b, (a, c) in enumerate(outs):
+                Rr[b, :a.shape[0]] = a
+                Rs[b, :c.shape[0]] = c
+            rad_arr = np.full((batch,), radius, np.float64)
+        else:
+            if np.ndim(radius) == 0:
+                thr = float(radius)
+                rad_arr = np.full((batch,), radius, np.float64)
+            else:
+                thr = t(np.asarray(radius, np.float32))
+                rad_arr = np.asarray(radius, np.float64)
+            Rr, Rs = R.construct_edges_from_states_batch(t(pos), thr, t(g["mask"]), t(g["tool_mask"]),
+                                                         topk=topk, connect_tools_all=connect)
+        n, recv, send = onehots_to_edges(Rr, Rs)
+        save("edges_" + name, pos=pos, mask=g["mask"], tool_mask=g["tool_mask"], radius=rad_arr,
+             radius_is_tensor=np.array(np.ndim(radius) != 0), topk=np.int32(topk), connect_tools_all=np.array(connect),
+             variant=np.array(variant), n_rel=n, recv=recv, send=send)
+        cases.append(name)
+
+    add("rope64_batch", "rope", 63, 3, "batch", spacing=0.1)
+    add("rope64_single", "rope", 63, 2, "single", spacing=0.1)
+    add("rope300_batch", "rope", 300, 2, "batch", spacing=0.2)
+    add("rope300s01_batch", "rope", 300, 1, "batch", spacing=0.1)
+    add("rope_thr04_batch", "rope", 120, 2, "batch", radius=0.4, spacing=0.1)      # fp32 r*r vs double r*r rounding
+    add("rope_thr04_single", "rope", 120, 2, "single", radius=0.4, spacing=0.1)
+    add("rope_persample_radius", "rope", 120, 3, "batch", radius=np.array([0.3, 0.5, 0.75], np.float32), spacing=0.1)
+    add("rope_padded_batch", "rope", 50, 2, "batch", n_pad=14, spacing=0.1)
+    add("rope_padded_single", "rope", 50, 2, "single", n_pad=14, spacing=0.1)
+    add("rope_tiny_topk", "rope", 6, 2, "batch", topk=10, spacing=0.1)              # N < topk
+    add("granular200_batch", "granular", 200, 2, "batch")
+    add("granular200_single", "granular", 200, 1, "single")
+    add("cloth256_batch", "cloth", 256, 2, "batch")
+    add("cloth256_single", "cloth", 256, 2, "single")
+    add("cloth64_far_batch", "cloth", 64, 2, "batch", tool_near=False)               # batch variant drops tool edges
+    add("cloth64_far_single", "cloth", 64, 2, "single", tool_near=False)
+    add("granular_connect_batch", "granular", 150, 2, "batch", connect=True)          # 5 tools + connect_tools_all
+    add("granular_connect_single", "granular", 150, 2, "single", connect=True)
+    del rng
+    return cases
+
+
+# ------------------------------------------------------------------ forward fixtures (row a5)
+def gen_forward(R):
+    def add(name, material, n_obj, batch, n_pad=0, decoder_scale=None, **kw):
+        model = build_model(R, material)
+        if decoder_scale is not None:
+            with torch.no_grad():
+                model.non_rigid_predictor.linear_2.weight *= decoder_scale
+                model.non_rigid_predictor.linear_2.bias *= decoder_scale
+        g = synth.make_graph_inputs(material, n_obj, batch, seed=3, n_pad=n_pad, **kw)
+        m = synth.MATERIALS[material]
+        Rr, Rs = R.construct_edges_from_states_batch(t(g["state"][:, -1]), float(m["radius"]), t(g["mask"]),
+                                                     t(g["tool_mask"]), topk=m["topk"],
+                                                     connect_tools_all=m["connect_tools_all"])
+        graph = dict(state=t(g["state"]), attrs=t(g["attrs"]), action=t(g["action"]), p_instance=t(g["p_instance"]),
+                     Rr=Rr, Rs=Rs)
+        graph[material + "_physics_param"] = t(g["phys"])
+        with torch.no_grad():
+            pred_pos, pred_motion = model(**graph)
+        n, recv, send = onehots_to_edges(Rr, Rs)
+        save("fwd_" + name, material=np.array(material), state=g["state"], attrs=g["attrs"], action=g["action"],
+             p_instance=g["p_instance"], phys=g["phys"], n_rel=n, recv=recv, send=send,
+             decoder_scale=np.float32(1.0 if decoder_scale is None else decoder_scale),
+             pred_pos=pred_pos.numpy(), pred_motion=pred_motion.numpy())
+
+    add("rope64", "rope", 63, 2, spacing=0.1)
+    add("rope301", "rope", 300, 1, spacing=0.2)                  # BASELINE configs[0]
+    add("rope_padded", "rope", 50, 2, n_pad=14, spacing=0.1)
+    add("rope_clamp", "rope", 63, 1, decoder_scale=5000.0, spacing=0.1)
+    add("granular205", "granular", 200, 2)
+    add("cloth257", "cloth", 256, 2)
+
+
+# ------------------------------------------------------------------ rollout fixtures (rows a9, a10, a11)
+def ppm_namespace(plan, device="cpu", radius=None):
+    material = plan["material"]
+    ns = types.SimpleNamespace()
+    ns.task_config = plan
+    ns.eef_num = plan["eef_num"]
+    ns.material = material
+    ns.material_dims = plan["material_dims"]
+    ns.material_indices = plan["material_indices"]
+    ns.adj_thresh = plan["adj_thresh"] if radius is None else radius
+    ns.physics_param = {material: torch.tensor([0.5]).repeat(plan["material_dims"][material])}
+    return ns
+
+
+def gen_rollout(R):
+    import contextlib
+    import io
+
+    def add(name, material, n_obj, bsz, n_look=1, len_lo=2, len_hi=6, **kw):
+        _, plan = load_cfg(material)
+        model = build_model(R, material)
+        ppm = ppm_namespace(plan)
+        state, act = synth.make_mpc_inputs(material, n_obj, bsz, n_look=n_look, seed=5, len_lo=len_lo, len_hi=len_hi, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = R.dynamics(t(state), t(act), model, "cpu", ppm)
+        save("dyn_" + name, material=np.array(material), state=state, action=act,
+             state_seqs=out["state_seqs"].numpy(), action_seqs=out["action_seqs"].numpy())
+
+    add("rope60", "rope", 60, 6, spacing=0.1)
+    add("rope60_look2", "rope", 60, 4, n_look=2, len_lo=1, len_hi=4, spacing=0.1)
+    add("granular80", "granular", 80, 4, len_lo=1, len_hi=4)        # 5-point pusher
+    add("cloth81", "cloth", 81, 4, len_lo=1, len_hi=4)               # connect_tools_all + gripper_enable
+
+    def add_masked(name, material, n_obj, n_slots, bsz, **kw):
+        _, plan = load_cfg(material)
+        model = build_model(R, material)
+        ppm = ppm_namespace(plan)
+        rng = np.random.default_rng(9)
+        state_init = np.zeros((bsz, n_slots, 3), np.float32)
+        state_mask = np.zeros((bsz, n_slots), bool)
+        acts = np.zeros((bsz, 4), np.float32)
+        for b in range(bsz):
+            nb = n_obj - 3 * b
+            obj, a = synth.make_mpc_inputs(material, nb, 1, seed=20 + b, len_lo=1, len_hi=5, **kw)
+            state_init[b, :nb] = obj
+            state_mask[b, :nb] = True
+            acts[b] = a[0, 0]
+        del rng
+        out = R.dynamics_masked(t(state_init), t(state_mask), t(acts), model, "cpu", ppm)
+        save("dynmask_" + name, material=np.array(material), state_init=state_init, state_mask=state_mask,
+             action=acts, state_seqs=out["state_seqs"].numpy(), action_seqs=out["action_seqs"].numpy())
+
+    add_masked("rope40", "rope", 40, 44, 3, spacing=0.1)
+    add_masked("granular60", "granular", 60, 64, 2)
+
+    # decode_action (row a11): truncation toward zero of the length field, fp32 trig
+    rng = np.random.default_rng(1)
+    a = rng.uniform(-4, 15, (5, 3, 4)).astype(np.float32)
+    for pl in (0.1, 0.2):
+        d, r = R.decode_action(t(a), push_length=pl)
+        save(f"decode_action_pl{int(pl * 10)}", action=a, push_length=np.float64(pl), decoded=d.numpy(), repeat=r.numpy())
+
+
+def gen_weights(R):
+    for material in ("rope", "granular", "cloth"):
+        model = build_model(R, material)
+        sd = {k: v.numpy() for k, v in model.state_dict().items()}
+        assert len(sd) == 22 and sum(v.size for v in sd.values()) == 252903
+        if material == "rope":
+            save("weights_seed0", **sd)
+        else:  # all three materials share dims, hence the same seed-0 init: keep one copy, assert the claim
+            ref = np.load(os.path.join(OUT, "weights_seed0.npz"))
+            assert all(np.array_equal(ref[k], sd[k]) for k in sd), material
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    R = import_reference()
+    gen_weights(R)
+    gen_edges(R)
+    gen_forward(R)
+    gen_rollout(R)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Import the AdaptiGraph reference (read-only, /root/reference) in THIS container.
+
+Only used by tools/gen_golden.py to produce tests/golden/*.npz.  It never ships:
+the GPU box has no /root/reference, and nothing under tests/ or the package
+imports this module.
+
+The hot-path modules import third-party packages at module import time that the
+hot functions never call (dgl, cv2, moviepy, h5py); those are replaced by empty
+module stubs so that the reference's own code runs unmodified.
+"""
+import sys
+import types
+
+REF_SRC = "/root/reference/src"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    if "dgl" not in sys.modules:
+        dgl = _stub("dgl")
+        dgl.geometry = _stub("dgl.geometry", farthest_point_sampler=None)
+    for n in ("cv2", "moviepy", "moviepy.editor", "h5py"):
+        if n not in sys.modules:
+            _stub(n)
+    from dynamics.gnn.model import DynamicsPredictor
+    from dynamics.dataset.graph import (construct_edges_from_states,
+                                        construct_edges_from_states_batch)
+    from dynamics.utils import truncate_graph, pad_torch
+    from planning.forward_dynamics import dynamics, dynamics_masked
+    from planning.plan_utils import decode_action
+    return types.SimpleNamespace(
+        DynamicsPredictor=DynamicsPredictor,
+        construct_edges_from_states=construct_edges_from_states,
+        construct_edges_from_states_batch=construct_edges_from_states_batch,
+        truncate_graph=truncate_graph, pad_torch=pad_torch,
+        dynamics=dynamics, dynamics_masked=dynamics_masked,
+        decode_action=decode_action)
