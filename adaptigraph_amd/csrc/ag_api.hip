@@ -1,0 +1,433 @@
+// ag_api.hip — C-ABI entry points of libadaptigraph_hip.so (see include/adaptigraph_hip.h).
+// Host-side only: argument checks, weight packing, workspace carving, kernel sequencing on the caller's stream.
+#include "../../include/adaptigraph_hip.h"
+#include "ag_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define AG_HIP(x)                                                                                    \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail(AG_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));          \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {   // bump allocator over the caller's workspace, 256-byte aligned
+    char *base;
+    size_t off = 0, cap;
+    Carver(void *p, size_t c) : base(static_cast<char *>(p)), cap(c) {}
+    template <class T> T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *r = reinterpret_cast<T *>(base + off);
+        off += n * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap && (base != nullptr || off == 0); }
+};
+
+// state_dict order (model.py:103-122)
+enum { W_PE0, B_PE0, W_PE1, B_PE1, W_PE2, B_PE2, W_RE0, B_RE0, W_RE1, B_RE1, W_RE2, B_RE2, W_PP, B_PP, W_RP, B_RP,
+       W_D0, B_D0, W_D1, B_D1, W_D2, B_D2, N_TENSORS };
+
+// Append one layer as n_tiles chunk images: 32 out-features x AG_WSTRIDE floats, columns [col0, col0+K) of W
+// in image columns [0, K), the bias (if any) in image column K, XOR-swizzled per ag_common.h.
+void pack_layer(std::vector<float> &dst, const float *W, int ld, int col0, int K, int n_out, const float *bias,
+                int n_tiles)
+{
+    auto at = [](int i, int k) { return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3); };
+    for (int ti = 0; ti < n_tiles; ++ti) {
+        const size_t base = dst.size();
+        dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
+        float *c = dst.data() + base;
+        for (int i = 0; i < 32; ++i) {
+            const int o = 32 * ti + i;
+            if (o >= n_out) continue;
+            for (int k = 0; k < K; ++k) c[at(i, k)] = W[(size_t)o * ld + col0 + k];
+            if (bias) c[at(i, K)] = bias[o];
+        }
+    }
+}
+
+}  // namespace
+
+struct ag_model {
+    ag_model_config cfg;
+    float *dev = nullptr;       // all packed streams, one allocation
+    size_t dev_floats = 0;
+    AgWeights w{};
+    // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
+    size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
+    unsigned long long *edge_counter = nullptr;
+};
+
+namespace {
+
+int pack_and_upload(ag_model *m, const float *const *t)
+{
+    const int F = m->cfg.nf, dn = m->cfg.attr_dim + m->cfg.phys_dim + m->cfg.action_dim;
+    const int de = 2 * m->cfg.attr_dim + 1 + 3 * m->cfg.n_his;
+    std::vector<float> s;
+    s.reserve((size_t)81 * AG_CHUNK_FLOATS);
+    const size_t o_node = s.size();
+    pack_layer(s, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
+    pack_layer(s, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
+    pack_layer(s, t[W_PE2], F, 0, F, F, t[B_PE2], AG_NT);
+    pack_layer(s, t[W_PP], 2 * F, 0, F, F, t[B_PP], AG_NT);        // Pn  = W_pp[:, :F] enc + b_pp
+    pack_layer(s, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);        // Hr  = W_rp[:, F:2F] h
+    pack_layer(s, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);    // Hs  = W_rp[:, 2F:3F] h
+    const size_t o_edge = s.size();
+    pack_layer(s, t[W_RE0], de, 0, de, F, t[B_RE0], AG_NT);
+    pack_layer(s, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
+    pack_layer(s, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
+    pack_layer(s, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);        // Eterm = W_rp[:, :F] enc_e + b_rp
+    const size_t o_mid = s.size();
+    pack_layer(s, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);        // W_pp[:, F:2F] agg
+    pack_layer(s, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);
+    pack_layer(s, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);
+    const size_t o_last = s.size();
+    pack_layer(s, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);
+    pack_layer(s, t[W_D0], F, 0, F, F, t[B_D0], AG_NT);
+    pack_layer(s, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
+    pack_layer(s, t[W_D2], F, 0, F, 3, t[B_D2], 1);
+    if (!m->dev) {
+        AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
+        m->dev_floats = s.size();
+    }
+    AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
+    m->w.node_encode = reinterpret_cast<const float4 *>(m->dev + o_node);
+    m->w.edge_encode = reinterpret_cast<const float4 *>(m->dev + o_edge);
+    m->w.node_mid = reinterpret_cast<const float4 *>(m->dev + o_mid);
+    m->w.node_last = reinterpret_cast<const float4 *>(m->dev + o_last);
+    return AG_OK;
+}
+
+struct FwdLayout {
+    size_t rows_pad, e_pad;
+};
+
+FwdLayout fwd_layout(int B, int N, int64_t e_cap)
+{
+    FwdLayout L;
+    L.rows_pad = align_up((size_t)B * N, AG_ROWS_PER_BLOCK);
+    L.e_pad = align_up((size_t)(e_cap > 0 ? e_cap : 1), AG_ROWS_PER_BLOCK);
+    return L;
+}
+
+void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
+{
+    const FwdLayout L = fwd_layout(B, N, e_cap);
+    a.h = c.take<float>(L.rows_pad * AG_FP);
+    a.pn = c.take<float>(L.rows_pad * AG_FP);
+    a.hr = c.take<float>(L.rows_pad * AG_FP);
+    a.hs = c.take<float>(L.rows_pad * AG_FP);
+    a.agg = c.take<float>(L.rows_pad * AG_FP);
+    a.eterm = c.take<float>(L.e_pad * AG_FP);
+}
+
+void carve_edges(Carver &c, AgEdgeArgs &a)
+{
+    const size_t rows = (size_t)a.B * a.N;
+    a.sel0 = c.take<int32_t>(rows * a.cap0);
+    a.sel = a.connect ? c.take<int32_t>(rows * a.cap) : nullptr;
+    a.deg = c.take<int32_t>(rows);
+    a.flag = c.take<int32_t>(a.B);
+    a.blk_sum = c.take<int32_t>(rows / 1024 + 2);
+}
+
+void edge_caps(int N, int topk, int connect, int max_tools, int *cap0, int *cap)
+{
+    *cap0 = N < topk ? N : topk;
+    *cap = *cap0 + (connect ? max_tools : 0);
+}
+
+struct Timed {   // RAII: bracket one kernel launch with an event pair when profiling is on
+    ag_model *m;
+    int k;
+    hipStream_t s;
+    hipEvent_t stop = nullptr;
+    Timed(ag_model *m_, int k_, hipStream_t s_) : m(m_), k(k_), s(s_)
+    {
+        if (!m->profiling) return;
+        if (m->ev_used[k] == m->ev[k].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            m->ev[k].emplace_back(a, b);
+        }
+        auto &pr = m->ev[k][m->ev_used[k]++];
+        (void)hipEventRecord(pr.first, s);
+        stop = pr.second;
+    }
+    ~Timed() { if (stop) (void)hipEventRecord(stop, s); }
+};
+
+void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
+    a.edge_counter = m->profiling ? m->edge_counter : nullptr;
+    { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
+    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
+    for (int p = 0; p < a.pstep; ++p) {
+        { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(a, s); }
+        { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, a, p == a.pstep - 1, s); }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ag_last_error(void) { return g_err.c_str(); }
+int ag_version(void) { return 1; }
+
+int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_model **out)
+{
+    if (!cfg || !weights || !out) return fail(AG_ERR_ARG, "ag_model_create: null argument");
+    // The kernels are compiled for the shipped model_config family (config/dynamics/{rope,granular,cloth}.yaml).
+    if (cfg->nf != AG_F) return fail(AG_ERR_CONFIG, "nf=%d unsupported (kernels built for %d)", cfg->nf, AG_F);
+    if (cfg->n_his != AG_NHIS) return fail(AG_ERR_CONFIG, "n_his=%d unsupported (built for %d)", cfg->n_his, AG_NHIS);
+    if (cfg->attr_dim != AG_ATTR || cfg->action_dim != 3)
+        return fail(AG_ERR_CONFIG, "attr_dim=%d action_dim=%d unsupported", cfg->attr_dim, cfg->action_dim);
+    if (cfg->phys_dim < 0 || cfg->attr_dim + cfg->phys_dim + cfg->action_dim >= AG_NODE_IN_MAX)
+        return fail(AG_ERR_CONFIG, "phys_dim=%d unsupported", cfg->phys_dim);
+    if (cfg->pstep < 1) return fail(AG_ERR_CONFIG, "pstep=%d unsupported", cfg->pstep);
+    for (int i = 0; i < N_TENSORS; ++i)
+        if (!weights[i]) return fail(AG_ERR_ARG, "ag_model_create: weight %d is null", i);
+    ag_model *m = new ag_model();
+    m->cfg = *cfg;
+    const int rc = pack_and_upload(m, weights);
+    if (rc != AG_OK) {
+        if (m->dev) (void)hipFree(m->dev);
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return AG_OK;
+}
+
+int ag_model_update_weights(ag_model *m, const float *const *weights)
+{
+    if (!m || !weights) return fail(AG_ERR_ARG, "ag_model_update_weights: null argument");
+    return pack_and_upload(m, weights);
+}
+
+int ag_model_destroy(ag_model *m)
+{
+    if (!m) return AG_OK;
+    for (auto &v : m->ev)
+        for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (m->edge_counter) (void)hipFree(m->edge_counter);
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+    return AG_OK;
+}
+
+int ag_profile_enable(ag_model *m, int enable)
+{
+    if (!m) return fail(AG_ERR_ARG, "ag_profile_enable: null model");
+    if (enable && !m->edge_counter) {
+        AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->edge_counter), sizeof(unsigned long long)));
+    }
+    if (enable) AG_HIP(hipMemset(m->edge_counter, 0, sizeof(unsigned long long)));
+    for (auto &u : m->ev_used) u = 0;
+    m->profiling = enable != 0;
+    return AG_OK;
+}
+
+int ag_profile_read(ag_model *m, double *ms, int64_t *launches, int64_t *edges)
+{
+    if (!m || !ms || !launches || !edges) return fail(AG_ERR_ARG, "ag_profile_read: null argument");
+    for (int k = 0; k < AG_K_COUNT; ++k) {
+        double tot = 0.0;
+        for (size_t i = 0; i < m->ev_used[k]; ++i) {
+            float t = 0.f;
+            AG_HIP(hipEventSynchronize(m->ev[k][i].second));
+            AG_HIP(hipEventElapsedTime(&t, m->ev[k][i].first, m->ev[k][i].second));
+            tot += t;
+        }
+        ms[k] = tot;
+        launches[k] = (int64_t)m->ev_used[k];
+    }
+    unsigned long long e = 0;
+    if (m->edge_counter) AG_HIP(hipMemcpy(&e, m->edge_counter, sizeof e, hipMemcpyDeviceToHost));
+    *edges = (int64_t)e;
+    return AG_OK;
+}
+
+int64_t ag_edge_capacity(int B, int N, int topk, int connect_tools_all, int max_tools)
+{
+    int cap0, cap;
+    edge_caps(N, topk, connect_tools_all, max_tools, &cap0, &cap);
+    return (int64_t)B * N * (connect_tools_all ? cap : cap0);
+}
+
+size_t ag_edges_workspace_bytes(int B, int N, int topk, int connect_tools_all, int max_tools)
+{
+    AgEdgeArgs a{};
+    a.B = B; a.N = N; a.connect = connect_tools_all;
+    edge_caps(N, topk, connect_tools_all, max_tools, &a.cap0, &a.cap);
+    Carver c(nullptr, 0);
+    carve_edges(c, a);
+    return align_up(c.off, 256);
+}
+
+int ag_build_edges(const float *pos, const uint8_t *mask, const uint8_t *tool_mask, const float *thr_sq, int topk,
+                   int connect_tools_all, int variant, int B, int N, int max_tools, int32_t *row_ptr,
+                   int32_t *edge_recv, int32_t *edge_send, int64_t e_cap, void *workspace, size_t workspace_bytes,
+                   ag_stream_t stream)
+{
+    if (!pos || !mask || !tool_mask || !thr_sq || !row_ptr || !edge_recv || !edge_send || !workspace)
+        return fail(AG_ERR_ARG, "ag_build_edges: null argument");
+    if (B < 1 || N < 1 || topk < 1 || topk > 64) return fail(AG_ERR_ARG, "ag_build_edges: B=%d N=%d topk=%d (1..64)", B, N, topk);
+    if (variant != AG_VARIANT_SINGLE && variant != AG_VARIANT_BATCH) return fail(AG_ERR_ARG, "bad variant %d", variant);
+    if ((int64_t)B * N >= (1ll << 31) / 64) return fail(AG_ERR_ARG, "B*N too large for int32 edge offsets");
+    if (e_cap < ag_edge_capacity(B, N, topk, connect_tools_all, max_tools))
+        return fail(AG_ERR_ARG, "ag_build_edges: e_cap %lld < ag_edge_capacity()", (long long)e_cap);
+    AgEdgeArgs a{};
+    a.pos = pos; a.mask = mask; a.tool = tool_mask; a.thr_sq = thr_sq;
+    a.topk = topk; a.connect = connect_tools_all ? 1 : 0; a.variant = variant; a.B = B; a.N = N; a.max_tools = max_tools;
+    edge_caps(N, topk, a.connect, max_tools, &a.cap0, &a.cap);
+    a.row_ptr = row_ptr; a.edge_recv = edge_recv; a.edge_send = edge_send;
+    a.pos_stride = (size_t)N * 3;
+    Carver c(workspace, workspace_bytes);
+    carve_edges(c, a);
+    if (!c.ok()) return fail(AG_ERR_WS, "ag_build_edges: workspace %zu < %zu bytes", workspace_bytes, c.off);
+    ag_launch_build_edges(a, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+size_t ag_forward_workspace_bytes(int B, int N, int64_t e_cap)
+{
+    AgFwdArgs a{};
+    Carver c(nullptr, 0);
+    carve_forward(c, a, B, N, e_cap);
+    return align_up(c.off, 256);
+}
+
+int ag_forward(ag_model *m, const float *state, const float *attrs, const float *action, const float *p_instance,
+               int n_instance, const float *phys, const int32_t *row_ptr, const int32_t *edge_recv,
+               const int32_t *edge_send, int64_t e_cap, int B, int N, int n_p, float *pred_pos, float *pred_motion,
+               void *workspace, size_t workspace_bytes, ag_stream_t stream)
+{
+    if (!m || !state || !attrs || !action || !p_instance || !row_ptr || !edge_recv || !edge_send || !pred_pos ||
+        !pred_motion || !workspace)
+        return fail(AG_ERR_ARG, "ag_forward: null argument");
+    if (m->cfg.phys_dim > 0 && !phys) return fail(AG_ERR_ARG, "ag_forward: phys is null");
+    if (B < 1 || N < 1 || n_p < 0 || n_p > N || n_instance < 0 || e_cap < 0 || e_cap > 0x7fffffff)
+        return fail(AG_ERR_ARG, "ag_forward: bad sizes B=%d N=%d n_p=%d e_cap=%lld", B, N, n_p, (long long)e_cap);
+    AgFwdArgs a{};
+    a.state = state; a.attrs = attrs; a.action = action; a.p_instance = p_instance; a.phys = phys;
+    a.row_ptr = row_ptr; a.edge_recv = edge_recv; a.edge_send = edge_send;
+    a.pred_pos = pred_pos; a.pred_motion = pred_motion;
+    a.B = B; a.N = N; a.n_p = n_p; a.n_inst = n_instance; a.phys_dim = m->cfg.phys_dim; a.e_cap = (int)e_cap;
+    a.pstep = m->cfg.pstep; a.clamp = m->cfg.motion_clamp;
+    Carver c(workspace, workspace_bytes);
+    carve_forward(c, a, B, N, e_cap);
+    if (!c.ok()) return fail(AG_ERR_WS, "ag_forward: workspace %zu < %zu bytes", workspace_bytes, c.off);
+    run_forward(m, a, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+static void carve_rollout(Carver &c, const ag_rollout_params *p, AgFwdArgs &f, AgEdgeArgs &e, float **state,
+                          float **pred_pos, float **pred_motion, int n_his)
+{
+    const int64_t e_cap = ag_edge_capacity(p->B, p->N, p->topk, p->connect_tools_all, p->max_tools);
+    const size_t rows = (size_t)p->B * p->N;
+    *state = c.take<float>(rows * n_his * 3);
+    *pred_pos = c.take<float>((size_t)p->B * p->n_p * 3 + 4);
+    *pred_motion = c.take<float>((size_t)p->B * p->n_p * 3 + 4);
+    e.row_ptr = c.take<int32_t>(rows + 1);
+    e.edge_recv = c.take<int32_t>((size_t)e_cap + 1);
+    e.edge_send = c.take<int32_t>((size_t)e_cap + 1);
+    e.B = p->B; e.N = p->N; e.connect = p->connect_tools_all ? 1 : 0;
+    edge_caps(p->N, p->topk, e.connect, p->max_tools, &e.cap0, &e.cap);
+    carve_edges(c, e);
+    carve_forward(c, f, p->B, p->N, e_cap);
+    f.e_cap = (int)e_cap;
+}
+
+size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
+{
+    if (!p) return 0;
+    AgFwdArgs f{};
+    AgEdgeArgs e{};
+    float *a, *b, *d;
+    Carver c(nullptr, 0);
+    carve_rollout(c, p, f, e, &a, &b, &d, AG_NHIS);
+    return align_up(c.off, 256);
+}
+
+int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, const float *delta, const float *attrs,
+               const float *p_instance, const float *phys, const uint8_t *mask, const uint8_t *tool_mask,
+               const uint8_t *obj_mask, const float *thr_sq, const int32_t *repeat, float *out_seq,
+               float *state_final, void *workspace, size_t workspace_bytes, ag_stream_t stream)
+{
+    if (!m || !p || !state0 || !delta || !attrs || !p_instance || !mask || !tool_mask || !thr_sq || !repeat ||
+        !out_seq || !workspace)
+        return fail(AG_ERR_ARG, "ag_rollout: null argument");
+    if (p->height_mode == AG_HEIGHT_MASKED_MEAN && !obj_mask) return fail(AG_ERR_ARG, "ag_rollout: obj_mask is null");
+    if (p->B < 1 || p->N < 1 || p->n_p < 1 || p->n_p > p->N || p->topk < 1 || p->topk > 64 || p->n_steps < 0)
+        return fail(AG_ERR_ARG, "ag_rollout: bad sizes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AgFwdArgs f{};
+    AgEdgeArgs e{};
+    float *state, *pred_pos, *pred_motion;
+    Carver c(workspace, workspace_bytes);
+    carve_rollout(c, p, f, e, &state, &pred_pos, &pred_motion, m->cfg.n_his);
+    if (!c.ok()) return fail(AG_ERR_WS, "ag_rollout: workspace %zu < %zu bytes", workspace_bytes, c.off);
+    const size_t state_bytes = (size_t)p->B * m->cfg.n_his * p->N * 3 * sizeof(float);
+    AG_HIP(hipMemcpyAsync(state, state0, state_bytes, hipMemcpyDeviceToDevice, s));
+
+    e.mask = mask; e.tool = tool_mask; e.thr_sq = thr_sq; e.topk = p->topk; e.variant = AG_VARIANT_BATCH;
+    e.max_tools = p->max_tools;
+    f.state = state; f.attrs = attrs; f.action = delta; f.p_instance = p_instance; f.phys = phys;
+    f.row_ptr = e.row_ptr; f.edge_recv = e.edge_recv; f.edge_send = e.edge_send;
+    f.pred_pos = pred_pos; f.pred_motion = pred_motion;
+    f.B = p->B; f.N = p->N; f.n_p = p->n_p; f.n_inst = p->n_instance; f.phys_dim = m->cfg.phys_dim;
+    f.pstep = m->cfg.pstep; f.clamp = m->cfg.motion_clamp;
+
+    AgStepArgs st{};
+    st.state = state; st.delta = delta; st.pred_pos = pred_pos; st.obj_mask = obj_mask; st.repeat = repeat;
+    st.out_seq = out_seq; st.B = p->B; st.N = p->N; st.n_p = p->n_p; st.H = m->cfg.n_his;
+    st.height_mode = p->height_mode; st.raise = p->gripper_raise;
+
+    const size_t plane = (size_t)p->N * 3;
+    for (int ai = 1; ai <= p->n_steps; ++ai) {
+        // edges on the current frame = state[:, -1] (forward_dynamics.py:125 / :171)
+        e.pos = state + (size_t)(m->cfg.n_his - 1) * plane;
+        e.pos_stride = (size_t)m->cfg.n_his * plane;
+        { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(e, s); }
+        run_forward(m, f, s);
+        st.step = ai;
+        { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(st, s); }
+    }
+    if (state_final) AG_HIP(hipMemcpyAsync(state_final, state, state_bytes, hipMemcpyDeviceToDevice, s));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+}  // extern "C"

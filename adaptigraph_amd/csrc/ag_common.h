@@ -1,0 +1,96 @@
+// ag_common.h — shared constants, layouts and internal kernel-launch prototypes (gfx950 only).
+//
+// Data layouts in HBM (all fp32 unless noted):
+//   row-major activation tables   [rows][AG_FP]      AG_FP = 160 (= nf_effect 150 padded to 5 x 32),
+//                                                    640-byte rows, columns 150..159 are zero
+//   packed ("fragment-image") node tables [rows/32][5 tiles][4 q][2 h][32 j][4 p]:
+//       element (row g, feature f) lives at (g/32)*5120 + (((f/32)*4 + (f%32)/8)*2 + (f%8)/4)*128 + (g%32)*4 + f%4,
+//       i.e. exactly the register image of the MFMA operand a lane holds, so a wave moves it with
+//       fully coalesced 16-byte accesses (used for tensors only the MLP kernels touch: h, Pn)
+//   CSR/COO adjacency: row_ptr[B*N+1] (global rows = b*N+i), edge_recv[E], edge_send[E] as GLOBAL node
+//       ids, edges sorted by (receiver, sender) == the reference's nonzero() order (graph.py:151)
+//   weight streams: per fused kernel, a sequence of 20480-byte chunk images [32 out-features][160]:
+//       columns [0,K) weights, column K the bias (K = fan-in), rest zero; element (i, k) is stored at
+//       i*160 + 4*((k/4) ^ ((i>>1)&7)) + k%4 (16-byte XOR swizzle -> conflict-free ds_read_b128),
+//       copied linearly into LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AG_F 150             // nf_particle = nf_relation = nf_effect (config/dynamics/*.yaml)
+#define AG_FP 160            // padded feature stride (5 MFMA tiles of 32)
+#define AG_NT 5              // 32-wide feature tiles
+#define AG_WSTRIDE 160       // row stride of a weight chunk image (floats); 16-byte columns XOR-swizzled
+#define AG_CHUNK_FLOATS 5120 // 32 out-features x 160 = 1280 float4 = 5 per thread of a 256-thread block
+#define AG_CHUNK_F4 1280
+#define AG_ROWS_PER_WAVE 32
+#define AG_MLP_THREADS 256
+#define AG_ROWS_PER_BLOCK 128
+#define AG_PACK_BLOCK (32 * AG_FP)
+#define AG_NHIS 4            // n_his compiled into the edge-feature prologue (config/dynamics/*.yaml n_his: 4)
+#define AG_ATTR 2            // attr_dim = rel_attr_dim = 2
+#define AG_EDGE_IN 17        // 2*attr + group + 3*n_his  (model.py:109-113)
+#define AG_NODE_IN_MAX 8     // attr + phys + action <= 8 (model.py:96-101)
+
+enum { AG_OK = 0, AG_ERR_ARG = -1, AG_ERR_HIP = -2, AG_ERR_WS = -3, AG_ERR_CONFIG = -4 };
+
+struct AgWeights {           // device pointers into the packed weight streams (float4-aligned)
+    const float4 *node_encode;   // PE0 PE1 PE2 | PPa(+b_pp) | Wr | Ws        30 chunks
+    const float4 *edge_encode;   // RE0 RE1 RE2 | We(+b_rp)                     20 chunks
+    const float4 *node_mid;      // PPb | Wr | Ws                               15 chunks
+    const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
+};
+
+struct AgFwdArgs {
+    // caller tensors (device)
+    const float *state;      // (B, H, N, 3)
+    const float *attrs;      // (B, N, 2)
+    const float *action;     // (B, N, 3)
+    const float *p_instance; // (B, n_p, n_inst)
+    const float *phys;       // (B, phys_dim)
+    const int32_t *row_ptr;  // (B*N + 1)
+    const int32_t *edge_recv, *edge_send;  // (E_cap) global node ids
+    float *pred_pos, *pred_motion;         // (B, n_p, 3)
+    // workspace tables
+    float *h, *pn;           // packed node tables
+    float *hr, *hs, *agg;    // row-major node tables
+    float *eterm;            // row-major edge table
+    int B, N, n_p, n_inst, phys_dim, e_cap, pstep;
+    float clamp;
+    unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
+};
+
+// kernel launchers (one translation unit each)
+void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
+void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
+void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s);
+void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hipStream_t s);
+
+struct AgEdgeArgs {
+    const float *pos;            // (B, N, 3) with pos_stride floats between samples
+    size_t pos_stride;
+    const uint8_t *mask, *tool;  // (B, N)
+    const float *thr_sq;         // (B) squared radius, already rounded per the builder variant
+    int topk, connect, variant, B, N, max_tools;
+    int cap0, cap;     // slots per row: cap0 = min(N, topk) after top-k; cap = cap0 + max_tools after connect_tools_all
+    int32_t *row_ptr, *edge_recv, *edge_send;
+    // workspace
+    int32_t *sel0;     // (B*N, cap0) top-k/radius senders (local ids), ascending
+    int32_t *sel;      // (B*N, cap)  final senders when connect_tools_all (else unused)
+    int32_t *deg;      // (B*N)
+    int32_t *flag;     // (B) connect_tools_all batch_mask
+    int32_t *blk_sum;  // scan partials
+};
+void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);
+
+struct AgStepArgs {
+    float *state;             // (B, H, N, 3) working copy, shifted in place
+    const float *delta;       // (B, N, 3) per-step tool motion ("action")
+    const float *pred_pos;    // (B, n_p, 3)
+    const uint8_t *obj_mask;  // (B, n_p) or nullptr; used by height mode 1
+    const int32_t *repeat;    // (B) action_repeat
+    float *out_seq;           // (B, n_p, 3) recorded when repeat == step
+    int B, N, n_p, H, step, height_mode;
+    float raise;              // gripper raise (0 when disabled)
+};
+void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s);

@@ -1,0 +1,262 @@
+// ag_edges.hip — radius-graph + per-receiver top-k adjacency, emitted as receiver-sorted CSR/COO.
+//
+// Replaces construct_edges_from_states (variant 0, src/dynamics/dataset/graph.py:38-89) and
+// construct_edges_from_states_batch (variant 1, graph.py:91-156), without the dense (B,N,N,3) difference
+// tensor, the (B,N,N) distance/top-k matrices or the one-hot (B,E,N) outputs, and with no host sync.
+//
+// Exactness contract (bit-for-bit edge sets; a single flipped edge moves the outputs by O(1e-2)):
+//   d_ij  = ((dx*dx + dy*dy) + dz*dz) in fp32 with separately rounded products (this file is compiled with
+//           -ffp-contract=off) — bit-identical to torch.sum(s_diff ** 2, -1) on the reference's CPU path
+//   masks : d = 1e10 unless mask[i] && mask[j]; d = 1e10 for tool-tool pairs            (graph.py:114,118)
+//   in radius  <=>  (d - thr) < 0                                                         (graph.py:125)
+//   row top-k : the k = min(N, topk) smallest d of the row; restricted to in-radius candidates this is the
+//           k nearest in-radius senders (every in-radius entry is smaller than every other entry);
+//           exact-distance ties go to the lower sender index (torch.topk leaves them unspecified)
+//   connect_tools_all : the two variants' override rules, including the batch variant's per-sample
+//           batch_mask and the tool->tool edges it keeps (graph.py:77-80 vs :134-144)
+//   order : (receiver, sender) ascending == adj_matrix.nonzero() row-major order (graph.py:151)
+#include "ag_common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 16;
+constexpr int kCand = 384;     // per-wave candidate list capacity; pruned to top-k whenever it could overflow
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// keep only the k best (d, j)-ordered candidates, preserving ascending-j order; returns new count
+__device__ int prune_topk(float *cd, int *cj, int cnt, int k, int lane)
+{
+    unsigned keepbits = 0;
+    for (int base = 0, ch = 0; base < cnt; base += 64, ++ch) {
+        const int idx = base + lane;
+        const bool have = idx < cnt;
+        const float d = have ? cd[idx] : 0.f;
+        const int jj = have ? cj[idx] : 0;
+        int rank = 0;
+        for (int t = 0; t < cnt; ++t) {
+            const float dt = cd[t];
+            const int jt = cj[t];
+            rank += (dt < d) || (dt == d && jt < jj);
+        }
+        if (have && rank < k) keepbits |= 1u << ch;
+    }
+    wave_lds_fence();
+    int newcnt = 0;
+    for (int base = 0, ch = 0; base < cnt; base += 64, ++ch) {
+        const int idx = base + lane;
+        const bool have = idx < cnt;
+        const float d = have ? cd[idx] : 0.f;
+        const int jj = have ? cj[idx] : 0;
+        const bool keep = (keepbits >> ch) & 1u;
+        const unsigned long long bal = __ballot(keep);
+        wave_lds_fence();   // all lanes hold their (d, j) before anyone overwrites a slot
+        if (keep) {
+            const int pos = newcnt + __popcll(bal & ((1ull << lane) - 1ull));
+            cd[pos] = d;
+            cj[pos] = jj;
+        }
+        newcnt += __popcll(bal);
+        wave_lds_fence();
+    }
+    return newcnt;
+}
+
+__global__ __launch_bounds__(256) void select_kernel(AgEdgeArgs a)
+{
+    __shared__ float s_d[4][kCand];
+    __shared__ int s_j[4][kCand];
+    const int b = blockIdx.y, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *cd = s_d[wave];
+    int *cj = s_j[wave];
+    const float *pos = a.pos + (size_t)b * a.pos_stride;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    const float thr = a.thr_sq[b];
+    const int k = N < a.topk ? N : a.topk;
+
+    for (int rr = wave; rr < kRowsPerBlock; rr += 4) {
+        const int i = blockIdx.x * kRowsPerBlock + rr;
+        if (i >= N) break;   // wave-uniform
+        const float xi = pos[i * 3], yi = pos[i * 3 + 1], zi = pos[i * 3 + 2];
+        const bool mi = mk[i], ti = tl[i];
+        int cnt = 0;
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + lane;
+            bool c = false;
+            float d = 0.f;
+            if (j < N) {
+                const float dx = xi - pos[j * 3], dy = yi - pos[j * 3 + 1], dz = zi - pos[j * 3 + 2];
+                d = (dx * dx + dy * dy) + dz * dz;
+                if (!(mi && mk[j])) d = 1e10f;
+                if (ti && tl[j]) d = 1e10f;
+                c = (d - thr) < 0.0f;
+            }
+            const unsigned long long bal = __ballot(c);
+            if (bal) {
+                if (cnt + 64 > kCand) {   // wave-uniform; keeps the append below in bounds
+                    cnt = prune_topk(cd, cj, cnt, k, lane);
+                }
+                if (c) {
+                    const int p = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                    cd[p] = d;
+                    cj[p] = j;
+                }
+                cnt += __popcll(bal);
+                wave_lds_fence();
+            }
+        }
+        if (cnt > k) cnt = prune_topk(cd, cj, cnt, k, lane);
+        const size_t row = (size_t)b * N + i;
+        const int jsel = lane < cnt ? cj[lane] : -1;
+        if (lane < cnt) a.sel0[row * a.cap0 + lane] = jsel;
+        if (lane == 0) a.deg[row] = cnt;       // provisional when connect_tools_all: finalize_connect_kernel rewrites it
+        if (a.connect) {
+            // batch_mask (graph.py:123,135): some tool receiver keeps an edge from a non-tool sender
+            const bool hit = ti && lane < cnt && !tl[jsel];
+            if (a.variant == 1 && __ballot(hit) && lane == 0) atomicOr(&a.flag[b], 1);
+        }
+        wave_lds_fence();
+    }
+}
+
+// connect_tools_all overrides: merge {kept object senders} with {all tool senders} in ascending order.
+__global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
+{
+    const int b = blockIdx.y, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const size_t row = (size_t)b * N + i;
+    const bool mi = mk[i], ti = tl[i];
+    const int deg0 = a.deg[row];
+    const int mysel = lane < deg0 ? a.sel0[row * a.cap0 + lane] : -1;
+    // single (graph.py:77-80): tool receivers end with no edges; batch (:134-144): gated by batch_mask,
+    // and tool receivers keep tool->tool edges (incl. the self loop) when it is set
+    const bool add_tools = mi && (a.variant == 1 ? (a.flag[b] != 0) : !ti);
+    const bool keep_sel = !ti;
+    int out = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        const bool inb = j < N;
+        const bool tj = inb && tl[j];
+        bool member = false;
+        if (keep_sel) {
+            for (int t = 0; t < deg0; ++t) {
+                const int st = __shfl(mysel, t);
+                member |= (st == j);
+            }
+            member = member && inb && !tj;
+        }
+        if (add_tools && tj) member = true;
+        const unsigned long long bal = __ballot(member);
+        if (member) {
+            const int p = out + __popcll(bal & ((1ull << lane) - 1ull));
+            if (p < a.cap) a.sel[row * a.cap + p] = j;
+        }
+        out += __popcll(bal);
+    }
+    if (lane == 0) a.deg[row] = out < a.cap ? out : a.cap;
+}
+
+// ---- exclusive scan of the per-row degrees -> row_ptr, then COO fill -----------------------------
+constexpr int kScanRows = 1024;   // rows per block (256 threads x 4)
+
+__device__ int block_exclusive_scan(int v, int *total)
+{
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a)
+{
+    const int rows = a.B * a.N;
+    const int r0 = blockIdx.x * kScanRows + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (r0 + u < rows) ? a.deg[r0 + u] : 0;
+    int total;
+    block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) a.blk_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_blocks_kernel(AgEdgeArgs a, int nblk)
+{
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 256) {
+        const int idx = base + threadIdx.x;
+        const int v = idx < nblk ? a.blk_sum[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int c = carry;
+        if (idx < nblk) a.blk_sum[idx] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.row_ptr[a.B * a.N] = carry;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
+{
+    const int rows = a.B * a.N;
+    const int r0 = blockIdx.x * kScanRows + threadIdx.x * 4;
+    int d[4], s = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { d[u] = (r0 + u < rows) ? a.deg[r0 + u] : 0; s += d[u]; }
+    int total;
+    int off = a.blk_sum[blockIdx.x] + block_exclusive_scan(s, &total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = r0 + u;
+        if (row < rows) {
+            a.row_ptr[row] = off;
+            const int gbase = (row / a.N) * a.N;   // global id of the graph's node 0
+            for (int t = 0; t < d[u]; ++t) {
+                a.edge_recv[off + t] = row;
+                a.edge_send[off + t] = gbase + sel[(size_t)row * cap + t];
+            }
+            off += d[u];
+        }
+    }
+}
+
+}  // namespace
+
+void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
+{
+    const int rows = a.B * a.N;
+    if (a.connect) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
+    hipLaunchKernelGGL(select_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), 0, s, a);
+    const int32_t *sel = a.sel0;
+    int cap = a.cap0;
+    if (a.connect) {
+        hipLaunchKernelGGL(finalize_connect_kernel, dim3((a.N + 3) / 4, a.B), dim3(256), 0, s, a);
+        sel = a.sel;
+        cap = a.cap;
+    }
+    const int nblk = (rows + kScanRows - 1) / kScanRows;
+    hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, a, nblk);
+    hipLaunchKernelGGL(fill_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
+}

@@ -1,0 +1,68 @@
+// ag_rollout.hip — per-step state update of the batched rollout, entirely on device.
+//
+// Replaces the tail of the inner loop of dynamics() / dynamics_masked()
+// (src/planning/forward_dynamics.py:160-176 / :356-372):
+//     pred_state_seq[repeat == ai] = pred_state                       record-on-repeat
+//     y_cur   = min_i pred_y            (dynamics, :163)   |  masked mean (dynamics_masked, :359)
+//     eef_cur = state[-1, tools] + action[tools]; eef_cur.y = y_cur (+ gripper raise)   (:164-168)
+//     state   = cat([state[1:], cat([pred_state, eef_cur])])           history shift     (:170,176)
+// One workgroup per sample; no host synchronisation (the reference syncs via .item() every step).
+#include "ag_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
+{
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pred = a.pred_pos + (size_t)b * a.n_p * 3;
+
+    float y;
+    if (a.height_mode == 0) {
+        float m = INFINITY;
+        for (int i = tid; i < a.n_p; i += 256) m = fminf(m, pred[i * 3 + 1]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        y = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    } else {
+        const uint8_t *mk = a.obj_mask + (size_t)b * a.n_p;
+        float s = 0.f, c = 0.f;
+        for (int i = tid; i < a.n_p; i += 256) {
+            const float w = mk[i] ? 1.f : 0.f;
+            s += pred[i * 3 + 1] * w;
+            c += w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+        if (lane == 0) { red[wave] = s; red[4 + wave] = c; }
+        __syncthreads();
+        y = ((red[0] + red[1]) + (red[2] + red[3])) / ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+    y += a.raise;
+
+    if (a.repeat[b] == a.step) {
+        float *o = a.out_seq + (size_t)b * a.n_p * 3;
+        for (int k = tid; k < a.n_p * 3; k += 256) o[k] = pred[k];
+    }
+    float *st = a.state + (size_t)b * a.H * a.N * 3;
+    const float *dl = a.delta + (size_t)b * a.N * 3;
+    const int plane = a.N * 3;
+    for (int k = tid; k < plane; k += 256) {
+        const int n = k / 3, c = k - n * 3;
+        const float last = st[(size_t)(a.H - 1) * plane + k];
+        for (int h = 0; h + 1 < a.H; ++h) st[(size_t)h * plane + k] = st[(size_t)(h + 1) * plane + k];
+        float nv;
+        if (n < a.n_p) nv = pred[k];
+        else nv = (c == 1) ? y : last + dl[k];
+        st[(size_t)(a.H - 1) * plane + k] = nv;
+    }
+}
+
+}  // namespace
+
+void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B), dim3(256), 0, s, a);
+}

@@ -1,0 +1,171 @@
+"""Batched multi-step rollout drivers on the HIP engine — drop-in for src/planning/forward_dynamics.py.
+
+`dynamics(state, action, model, device, ppm_optimizer, physics_param=None)` (:11-205) and
+`dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer, physics_param=None)` (:208-399)
+keep the reference signatures and return dicts.  The per-sample set-up (tool key-points from the decoded
+action) is a handful of tiny device tensor ops; the inner loop — edges -> GNN forward -> record-on-repeat ->
+tool advance -> history shift -> edge rebuild — is one `ag_rollout` call with no host synchronisation
+(the reference syncs three times per step: truncate_graph, n_rels.max().item(), pad_torch).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .graph import threshold_sq, workspace, _stream_ptr
+from .plan_utils import decode_action
+
+
+def _u8(t):
+    return t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8).contiguous()
+
+
+def rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr_sq, repeat, n_steps, topk,
+            connect_tools_all, max_tools, height_mode=_lib.AG_HEIGHT_MIN, obj_mask=None, gripper_raise=0.0,
+            return_state=False):
+    """Native inner loop (forward_dynamics.py:156-197).  All tensors on the model's GPU.
+    state0 (B,H,N,3), delta (B,N,3), attrs (B,N,2), p_instance (B,n_p,I), phys (B,P), mask/tool_mask (B,N) bool,
+    thr_sq (B,), repeat (B,) int32 -> out_seq (B,n_p,3): prediction of step repeat[b] (zeros if never reached)."""
+    L = _lib.lib()
+    dev = state0.device
+    B, H, N, _ = state0.shape
+    n_p, n_inst = p_instance.shape[1], p_instance.shape[2]
+    prm = _lib.RolloutParams(B, N, n_p, n_inst, int(topk), 1 if connect_tools_all else 0, int(max_tools), int(n_steps),
+                             int(height_mode), float(gripper_raise))
+    out_seq = torch.zeros((B, n_p, 3), dtype=torch.float32, device=dev)
+    state_final = torch.empty_like(state0, dtype=torch.float32) if return_state else None
+    ws = workspace(dev, L.ag_rollout_workspace_bytes(ctypes.byref(prm)))
+    state0 = state0.contiguous().float()
+    delta = delta.contiguous().float()
+    attrs = attrs.contiguous().float()
+    p_instance = p_instance.contiguous().float()
+    phys = phys.to(dev, torch.float32).contiguous()
+    mask_u8, tool_u8 = _u8(mask), _u8(tool_mask)
+    obj_u8 = _u8(obj_mask) if obj_mask is not None else None
+    repeat = repeat.to(dev, torch.int32).contiguous()
+    thr_sq = thr_sq.contiguous()
+    h = model.handle(dev)
+    with torch.cuda.device(dev):
+        rc = L.ag_rollout(h, ctypes.byref(prm), state0.data_ptr(), delta.data_ptr(), attrs.data_ptr(),
+                          p_instance.data_ptr(), phys.data_ptr(), mask_u8.data_ptr(), tool_u8.data_ptr(),
+                          obj_u8.data_ptr() if obj_u8 is not None else None, thr_sq.data_ptr(), repeat.data_ptr(),
+                          out_seq.data_ptr(), state_final.data_ptr() if return_state else None, ws.data_ptr(),
+                          ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "ag_rollout")
+    return (out_seq, state_final) if return_state else out_seq
+
+
+def _place_tool(task, decoded, theta, y, device):
+    """Tool key-points and per-step delta from a decoded action (forward_dynamics.py:42-81 / :237-276)."""
+    bsz = decoded.shape[0]
+    pts = task["pusher_points"]
+    ratio = task["sim_real_ratio"]
+    n_t = len(pts)
+    eef = torch.zeros((bsz, n_t, 3), device=device)
+    dlt = torch.zeros((bsz, n_t, 3), device=device)
+    dlt[:, :, 0] = (decoded[:, 2] - decoded[:, 0]).unsqueeze(1)
+    dlt[:, :, 2] = (decoded[:, 3] - decoded[:, 1]).unsqueeze(1)
+    eef[:, :, 1] = y[:, None]
+    if n_t == 1:
+        eef[:, 0, 0] = decoded[:, 0]
+        eef[:, 0, 2] = decoded[:, 1]
+    elif n_t == 5:
+        eef[:, 0, 0] = decoded[:, 0]
+        eef[:, 0, 2] = decoded[:, 1]
+        for i in range(1, 5):
+            off = float(pts[i][1]) * ratio
+            eef[:, i, 0] = decoded[:, 0] + off * torch.sin(theta)
+            eef[:, i, 2] = decoded[:, 1] - off * torch.cos(theta)
+    else:
+        raise NotImplementedError("pusher not implemented")
+    raise_by = 0.01 * ratio if task["gripper_enable"] else 0.0
+    if raise_by:
+        eef[:, :, 1] += raise_by
+    return eef, dlt, raise_by
+
+
+def _physics(ppm_optimizer, physics_param, bsz, device):
+    physics_param = ppm_optimizer.physics_param if physics_param is None else physics_param
+    material = ppm_optimizer.material
+    dims = ppm_optimizer.material_dims
+    assert len(dims) == 1 and material in dims, "Only support single material."
+    return physics_param[material].to(device, torch.float32)[None].repeat(bsz, 1)
+
+
+@torch.no_grad()
+def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
+    task = ppm_optimizer.task_config
+    n_his, push_length = task["n_his"], task["push_length"]
+    state = state.to(device, torch.float32)
+    action = action.to(device, torch.float32)
+    bsz, n_look = action.shape[0], action.shape[1]
+    decoded, repeat = decode_action(action, push_length=push_length)
+    n_obj, n_t = state.shape[0], ppm_optimizer.eef_num
+    N = n_obj + n_t
+
+    attrs = torch.zeros((bsz, N, 2), device=device)
+    attrs[:, :n_obj, 0] = 1.0
+    attrs[:, n_obj:, 1] = 1.0
+    p_instance = torch.zeros((bsz, n_obj, task["max_n"]), device=device)
+    p_instance[:, :, 0] = 1.0
+    mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
+    tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
+    tool_mask[:, n_obj:] = True
+    phys = _physics(ppm_optimizer, physics_param, bsz, device)
+    thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
+    max_steps = repeat.max(dim=0).values.tolist()     # ONE host sync per call (reference: one per look-ahead + 3 per step)
+
+    seq = torch.zeros((bsz, n_look, n_obj, 3), device=device)
+    obj = state[None].expand(bsz, n_obj, 3)
+    for li in range(n_look):
+        if li > 0:
+            obj = seq[:, li - 1]
+        y = obj[:, :, 1].min(dim=1).values
+        eef, dlt, raise_by = _place_tool(task, decoded[:, li], action[:, li, 2], y, device)
+        state0 = torch.empty((bsz, n_his, N, 3), device=device)
+        state0[:, :, :n_obj] = obj[:, None]
+        state0[:, :, n_obj:] = eef[:, None]
+        delta = torch.zeros((bsz, N, 3), device=device)
+        delta[:, n_obj:] = dlt
+        seq[:, li] = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, repeat[:, li],
+                             max_steps[li], task["topk"], task["connect_tools_all"], n_t,
+                             _lib.AG_HEIGHT_MIN, None, raise_by)
+    return {"state_seqs": seq, "action_seqs": decoded}
+
+
+@torch.no_grad()
+def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer, physics_param=None):
+    task = ppm_optimizer.task_config
+    n_his, push_length = task["n_his"], task["push_length"]
+    state = state_init.to(device, torch.float32)
+    state_mask = state_mask.to(device)
+    action = action.to(device, torch.float32)
+    bsz, n_obj = state.shape[0], state.shape[1]
+    decoded, repeat = decode_action(action[:, None], push_length=push_length)
+    decoded, repeat = decoded[:, 0], repeat[:, 0]
+    n_t = ppm_optimizer.eef_num
+    N = n_obj + n_t
+
+    cnt = state_mask.sum(dim=1)
+    y = (state[:, :, 1] * state_mask).sum(dim=1) / cnt                            # forward_dynamics.py:235
+    eef, dlt, raise_by = _place_tool(task, decoded, action[:, 2], y, device)
+    state0 = torch.empty((bsz, n_his, N, 3), device=device)
+    state0[:, :, :n_obj] = state[:, None]
+    state0[:, :, n_obj:] = eef[:, None]
+    delta = torch.zeros((bsz, N, 3), device=device)
+    delta[:, n_obj:] = dlt
+    attrs = torch.zeros((bsz, N, 2), device=device)
+    attrs[:, :n_obj, 0] = state_mask.float()
+    attrs[:, n_obj:, 1] = 1.0
+    p_instance = torch.zeros((bsz, n_obj, task["max_n"]), device=device)           # first `count` slots, :292-300
+    p_instance[:, :, 0] = (torch.arange(n_obj, device=device)[None] < cnt[:, None]).float()
+    mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
+    mask[:, :n_obj] = state_mask.bool()
+    tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
+    tool_mask[:, n_obj:] = True
+    phys = _physics(ppm_optimizer, physics_param, bsz, device)
+    thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
+    n_steps = int(repeat.max().item())
+    seq = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, repeat, n_steps, task["topk"],
+                  task["connect_tools_all"], n_t, _lib.AG_HEIGHT_MASKED_MEAN, state_mask.bool(), raise_by)
+    return {"state_seqs": seq, "action_seqs": decoded}

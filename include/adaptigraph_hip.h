@@ -1,0 +1,121 @@
+/*
+ * adaptigraph_hip.h — C ABI of libadaptigraph_hip.so, the MI355X (gfx950) engine for AdaptiGraph's
+ * message-passing rollout hot path.
+ *
+ * The reference has no FFI/plugin layer: its boundary is a Python call surface.  Each
+ * entry point below names the reference symbol it stands behind; INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.  Conventions:
+ *   - every data pointer is a DEVICE pointer (tensor.data_ptr()) unless marked host; fp32 / int32 / uint8
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises the host
+ *   - the caller owns all memory, including the scratch `workspace` sized by the *_workspace_bytes queries;
+ *     the library allocates only the packed weights inside ag_model
+ *   - return 0 on success, negative on error; ag_last_error() gives the message (thread-local)
+ *   - one ag_model may be used from one host thread at a time; distinct models/streams may run concurrently
+ *   - inputs are never mutated; outputs are fully overwritten
+ */
+#ifndef ADAPTIGRAPH_HIP_H
+#define ADAPTIGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ag_model ag_model;
+typedef void *ag_stream_t; /* hipStream_t */
+
+enum { AG_VARIANT_SINGLE = 0, AG_VARIANT_BATCH = 1 };
+enum { AG_HEIGHT_MIN = 0, AG_HEIGHT_MASKED_MEAN = 1 };
+
+/* Derived from model_config / material_config / dataset_config exactly as DynamicsPredictor.__init__ does
+ * (src/dynamics/gnn/model.py:63-126). */
+typedef struct ag_model_config {
+    int32_t nf;           /* nf_particle == nf_relation == nf_effect (150)                  model.py:79-81   */
+    int32_t n_his;        /* dataset_config['n_his'] (4)                                    model.py:77      */
+    int32_t attr_dim;     /* model_config['attr_dim'] == rel_attr_dim (2)                   model.py:98,110  */
+    int32_t phys_dim;     /* #physics_params with use: True                                 model.py:91-94   */
+    int32_t action_dim;   /* 3                                                              model.py:99      */
+    int32_t pstep;        /* propagation steps (3)                                          model.py:278     */
+    float motion_clamp;   /* 100                                                            model.py:85      */
+} ag_model_config;
+
+const char *ag_last_error(void);
+int ag_version(void);
+
+/* DynamicsPredictor.__init__ + load_state_dict (model.py:63-126; checkpoint layout SURVEY.md §8b):
+ * `weights` = 22 HOST pointers to fp32 tensors in state_dict order
+ *   particle_encoder.model.{0,2,4}.{weight,bias}, relation_encoder.model.{0,2,4}.{weight,bias},
+ *   particle_propagator.linear.{weight,bias}, relation_propagator.linear.{weight,bias},
+ *   non_rigid_predictor.linear_{0,1,2}.{weight,bias}           (nn.Linear weight = (out,in) row-major).
+ * Packs them into MFMA-ready chunk streams on the current HIP device. */
+int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_model **out);
+int ag_model_update_weights(ag_model *m, const float *const *weights);
+int ag_model_destroy(ag_model *m);
+
+/* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */
+int64_t ag_edge_capacity(int B, int N, int topk, int connect_tools_all, int max_tools);
+size_t ag_edges_workspace_bytes(int B, int N, int topk, int connect_tools_all, int max_tools);
+
+/* construct_edges_from_states (variant SINGLE, src/dynamics/dataset/graph.py:38-89) and
+ * construct_edges_from_states_batch (variant BATCH, graph.py:91-156) for B samples at once.
+ *   pos (B,N,3) f32; mask, tool_mask (B,N) u8; thr_sq (B) f32 = squared radius rounded as the variant does
+ *   (SINGLE: (float)((double)r*r), BATCH: (float)r*(float)r); topk <= 64; max_tools >= #tool slots per sample.
+ * Out: row_ptr (B*N+1) i32 over global rows b*N+i (row_ptr[B*N] = total edges, stays on device),
+ *      edge_recv / edge_send (e_cap) i32 GLOBAL node ids in the reference's (receiver, sender) order.
+ * Equivalent dense outputs: Rr[b, e - row_ptr[b*N], edge_recv[e] - b*N] = 1 (graph.py:152-155). */
+int ag_build_edges(const float *pos, const uint8_t *mask, const uint8_t *tool_mask, const float *thr_sq, int topk,
+                   int connect_tools_all, int variant, int B, int N, int max_tools, int32_t *row_ptr,
+                   int32_t *edge_recv, int32_t *edge_send, int64_t e_cap, void *workspace, size_t workspace_bytes,
+                   ag_stream_t stream);
+
+size_t ag_forward_workspace_bytes(int B, int N, int64_t e_cap);
+
+/* DynamicsPredictor.forward (model.py:129-313) on a CSR adjacency instead of one-hot Rr/Rs.
+ *   state (B,n_his,N,3), attrs (B,N,2), action (B,N,3), p_instance (B,n_p,n_instance), phys (B,phys_dim)
+ *   row_ptr/edge_recv/edge_send as produced by ag_build_edges (edges sorted by receiver).
+ * Out: pred_pos, pred_motion (B,n_p,3). */
+int ag_forward(ag_model *m, const float *state, const float *attrs, const float *action, const float *p_instance,
+               int n_instance, const float *phys, const int32_t *row_ptr, const int32_t *edge_recv,
+               const int32_t *edge_send, int64_t e_cap, int B, int N, int n_p, float *pred_pos, float *pred_motion,
+               void *workspace, size_t workspace_bytes, ag_stream_t stream);
+
+/* Inner rollout loop of dynamics() / dynamics_masked() (src/planning/forward_dynamics.py:125-197 / :319-393):
+ * edges -> forward -> record-on-repeat -> tool advance -> history shift -> edge rebuild, n_steps times,
+ * with no host synchronisation. */
+typedef struct ag_rollout_params {
+    int32_t B, N, n_p;            /* samples, slots per sample (objects + tools), object slots                */
+    int32_t n_instance;
+    int32_t topk, connect_tools_all, max_tools;
+    int32_t n_steps;              /* max(action_repeat), forward_dynamics.py:156                              */
+    int32_t height_mode;          /* AG_HEIGHT_MIN (:163) or AG_HEIGHT_MASKED_MEAN (:359)                     */
+    float gripper_raise;          /* 0.01 * sim_real_ratio if gripper_enable else 0 (:167-168)                */
+} ag_rollout_params;
+
+size_t ag_rollout_workspace_bytes(const ag_rollout_params *p);
+
+/*   state0 (B,n_his,N,3) initial history incl. tool slots; delta (B,N,3) per-step tool motion (graph["action"]);
+ *   attrs (B,N,2); p_instance (B,n_p,n_instance); phys (B,phys_dim); mask/tool_mask (B,N) u8;
+ *   obj_mask (B,n_p) u8 (only read in MASKED_MEAN mode, may be NULL otherwise); thr_sq (B);
+ *   repeat (B) i32 = action_repeat.
+ * Out: out_seq (B,n_p,3) = prediction of step repeat[b] (rows with repeat outside 1..n_steps are left untouched);
+ *      state_final (B,n_his,N,3) optional (may be NULL). */
+int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, const float *delta, const float *attrs,
+               const float *p_instance, const float *phys, const uint8_t *mask, const uint8_t *tool_mask,
+               const uint8_t *obj_mask, const float *thr_sq, const int32_t *repeat, float *out_seq,
+               float *state_final, void *workspace, size_t workspace_bytes, ag_stream_t stream);
+
+/* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
+ * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
+ * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the
+ * launch count, and for AG_K_EDGE_ENCODE the summed number of edges processed (units for the roofline). */
+enum { AG_K_EDGES = 0, AG_K_NODE_ENCODE = 1, AG_K_EDGE_ENCODE = 2, AG_K_AGGREGATE = 3, AG_K_NODE_UPDATE = 4,
+       AG_K_ROLLOUT_STEP = 5, AG_K_COUNT = 6 };
+int ag_profile_enable(ag_model *m, int enable);
+int ag_profile_read(ag_model *m, double *ms /*AG_K_COUNT*/, int64_t *launches /*AG_K_COUNT*/, int64_t *edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPTIGRAPH_HIP_H */

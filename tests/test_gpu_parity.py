@@ -1,0 +1,279 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle on the same seeded inputs.  Needs an MI355X (`-m gpu`).
+
+Bars: edge lists bit-exact; fp32 outputs within 1e-4 max-abs of the reference forward on identical graphs
+(BASELINE.json north_star); measured deviation is ~1e-6, the tolerances below keep a margin but would catch
+any structural error (a wrong edge or column block moves outputs by >= 1e-2).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden
+from adaptigraph_amd import _lib, configs, synth
+from adaptigraph_amd import graph as aggraph
+from adaptigraph_amd.forward_dynamics import dynamics, dynamics_masked, rollout
+from adaptigraph_amd.model import DynamicsPredictor
+from oracle import ag_oracle as ago
+
+pytestmark = pytest.mark.gpu
+TOL_FWD = 1e-4        # north_star gate (single forward, identical graphs)
+TOL_TIGHT = 2e-5      # what fp32 MFMA chains actually achieve; used where inputs are small
+DEV = "cuda:0"
+
+
+def t(x, dtype=None):
+    r = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return r if dtype is None else r.to(dtype)
+
+
+@pytest.fixture(scope="module")
+def model(weights):
+    return make_model(weights)
+
+
+def make_model(weights, material="rope", decoder_scale=1.0):
+    m = DynamicsPredictor(configs.model_config(), configs.material_config(material), configs.dataset_config(material), DEV)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+    if decoder_scale != 1.0:
+        sd["non_rigid_predictor.linear_2.weight"] *= decoder_scale
+        sd["non_rigid_predictor.linear_2.bias"] *= decoder_scale
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+def lists_from(n_rel, recv, send):
+    return [(recv[b, :n], send[b, :n]) for b, n in enumerate(n_rel)]
+
+
+def csr_from_lists(n_rel, recv, send, N):
+    """golden/oracle per-sample edge lists -> CSREdges on the GPU (edges are already receiver-sorted)."""
+    B = len(n_rel)
+    r = np.concatenate([recv[b, :n] + b * N for b, n in enumerate(n_rel)]).astype(np.int32)
+    s = np.concatenate([send[b, :n] + b * N for b, n in enumerate(n_rel)]).astype(np.int32)
+    row_ptr = np.zeros(B * N + 1, np.int32)
+    np.add.at(row_ptr, r + 1, 1)
+    row_ptr = np.cumsum(row_ptr).astype(np.int32)
+    e = max(len(r), 1)
+    rr = np.zeros(e, np.int32)
+    ss = np.zeros(e, np.int32)
+    rr[:len(r)] = r
+    ss[:len(s)] = s
+    return aggraph.CSREdges(t(row_ptr), t(rr), t(ss), B, N, len(r))
+
+
+# ------------------------------------------------------------------------------------------ edge builder
+@pytest.mark.parametrize("name", golden_files("edges_"))
+def test_edges_golden_exact(name):
+    g = load_golden(name)
+    radius = t(g["radius"].astype(np.float32)) if bool(g["radius_is_tensor"]) else float(g["radius"][0])
+    csr = aggraph.build_edges(t(g["pos"]), radius, t(g["mask"]), t(g["tool_mask"]), int(g["topk"]),
+                              bool(g["connect_tools_all"]), str(g["variant"]), max_tools=int(g["tool_mask"].sum(1).max()))
+    got = csr.to_lists()
+    assert csr.n_rel().cpu().tolist() == g["n_rel"].tolist()
+    for b, (r, s) in enumerate(got):
+        n = g["n_rel"][b]
+        assert np.array_equal(r, g["recv"][b, :n]) and np.array_equal(s, g["send"][b, :n]), f"sample {b}"
+
+
+@pytest.mark.parametrize("material,n_obj,batch,variant,kw", [
+    ("rope", 1000, 3, "batch", dict(spacing=0.1)),            # BASELINE configs[1] graph size
+    ("rope", 1000, 2, "single", dict(spacing=0.1)),
+    ("granular", 2000, 2, "batch", {}),                        # configs[2]: top-k 20 saturated, 5 tools
+    ("cloth", 4096, 2, "batch", {}),                           # configs[3]: connect_tools_all, N = 4097
+    ("cloth", 4096, 1, "single", {}),
+    ("cloth", 1024, 2, "batch", dict(tool_near=False)),
+    ("rope", 700, 2, "batch", dict(dense=True)),               # dense blob: > 384 in-radius candidates per row (prune path)
+])
+def test_edges_vs_oracle_exact(material, n_obj, batch, variant, kw):
+    dense = kw.pop("dense", False) if isinstance(kw, dict) else False
+    kw = {k: v for k, v in kw.items() if k != "dense"}
+    g = synth.make_graph_inputs(material, n_obj, batch, seed=21, **kw)
+    m = synth.MATERIALS[material]
+    pos = g["state"][:, -1].copy()
+    if dense:
+        pos[:, :n_obj] = np.random.default_rng(5).uniform(0, 0.4, (batch, n_obj, 3)).astype(np.float32)
+    n_rel, recv, send = ago.build_edges(pos, m["radius"], g["mask"], g["tool_mask"], m["topk"], m["connect_tools_all"], variant)
+    csr = aggraph.build_edges(t(pos), m["radius"], t(g["mask"]), t(g["tool_mask"]), m["topk"], m["connect_tools_all"],
+                              variant, max_tools=g["n_tools"])
+    assert csr.n_rel().cpu().tolist() == n_rel.tolist()
+    for b, (r, s) in enumerate(csr.to_lists()):
+        assert np.array_equal(r, recv[b, :n_rel[b]]) and np.array_equal(s, send[b, :n_rel[b]]), f"sample {b}"
+
+
+def test_edges_dropin_dense_signature():
+    g = load_golden("edges_rope64_batch")
+    Rr, Rs = aggraph.construct_edges_from_states_batch(t(g["pos"]), 0.5, t(g["mask"]), t(g["tool_mask"]), topk=10,
+                                                       connect_tools_all=False)
+    assert Rr.shape == (3, int(g["n_rel"].max()), 64) and Rr.dtype == torch.float32
+    for b in range(3):
+        n = g["n_rel"][b]
+        assert torch.equal(Rr[b, :n].argmax(-1).cpu(), torch.from_numpy(g["recv"][b, :n]).long())
+        assert torch.equal(Rs[b, :n].argmax(-1).cpu(), torch.from_numpy(g["send"][b, :n]).long())
+        assert Rr[b, n:].abs().sum() == 0
+    g = load_golden("edges_cloth256_single")
+    Rr, Rs = aggraph.construct_edges_from_states(t(g["pos"][0]), 0.75, t(g["mask"][0]), t(g["tool_mask"][0]), topk=5,
+                                                 connect_tools_all=True)
+    assert Rr.shape == (int(g["n_rel"][0]), 257)
+    assert torch.equal(Rs.argmax(-1).cpu(), torch.from_numpy(g["send"][0, :g["n_rel"][0]]).long())
+
+
+# ------------------------------------------------------------------------------------------ forward
+@pytest.mark.parametrize("name", golden_files("fwd_"))
+def test_forward_golden(name, weights):
+    g = load_golden(name)
+    material = str(g["material"])
+    m = make_model(weights, material, float(g["decoder_scale"]))
+    N = g["attrs"].shape[1]
+    csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
+    kw = {material + "_physics_param": t(g["phys"])}
+    pos, mot = m(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), action=t(g["action"]), **kw)
+    scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_TIGHT * scale
+    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_TIGHT * scale
+
+
+def test_forward_dense_onehot_inputs_dropin(weights, model):
+    """model(**graph) with the reference's dict, dense Rr/Rs padded with all-zero rows (pad_torch, utils.py:37-46)."""
+    g = load_golden("fwd_rope64")
+    B, N = g["attrs"].shape[:2]
+    E = int(g["n_rel"].max()) + 37
+    Rr = torch.zeros(B, E, N, device=DEV)
+    Rs = torch.zeros(B, E, N, device=DEV)
+    for b in range(B):
+        n = g["n_rel"][b]
+        Rr[b, torch.arange(n), t(g["recv"][b, :n]).long()] = 1
+        Rs[b, torch.arange(n), t(g["send"][b, :n]).long()] = 1
+    graph = dict(state=t(g["state"]), attrs=t(g["attrs"]), Rr=Rr, Rs=Rs, p_instance=t(g["p_instance"]),
+                 action=t(g["action"]), rope_physics_param=t(g["phys"]), obj_mask=None, p_rigid=torch.zeros(B, 1))
+    pos, mot = model(**graph)
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_TIGHT
+    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_TIGHT
+
+
+@pytest.mark.parametrize("material,n_obj,batch,kw", [
+    ("rope", 1000, 2, dict(spacing=0.1)),
+    ("granular", 2000, 1, {}),
+    ("cloth", 4096, 1, {}),
+    ("rope", 93, 5, dict(spacing=0.1, n_pad=7)),             # ragged: rows not a multiple of 32/128, padded slots
+])
+def test_forward_vs_oracle(material, n_obj, batch, kw, weights):
+    g = synth.make_graph_inputs(material, n_obj, batch, seed=4, **kw)
+    mm = synth.MATERIALS[material]
+    m = make_model(weights, material)
+    pos_now = g["state"][:, -1]
+    csr = aggraph.build_edges(t(pos_now), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"],
+                              mm["connect_tools_all"], "batch", max_tools=g["n_tools"])
+    n_rel, recv, send = ago.build_edges(pos_now, mm["radius"], g["mask"], g["tool_mask"], mm["topk"],
+                                        mm["connect_tools_all"], "batch")
+    ref_pos, ref_mot = ago.forward(weights, g["state"], g["attrs"], g["action"], g["p_instance"], g["phys"], n_rel, recv, send)
+    kwp = {material + "_physics_param": t(g["phys"])}
+    pos, mot = m(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), action=t(g["action"]), **kwp)
+    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_TIGHT
+    assert np.abs(pos.cpu().numpy() - ref_pos).max() <= TOL_FWD
+
+
+def test_forward_no_edges_and_single_node(weights, model):
+    """Empty adjacency (all particles isolated and masked out of the graph) and a 1-particle cloud."""
+    g = synth.make_graph_inputs("rope", 5, 2, seed=1, spacing=10.0)
+    N = g["attrs"].shape[1]
+    empty = aggraph.CSREdges(torch.zeros(2 * N + 1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV),
+                             torch.zeros(1, dtype=torch.int32, device=DEV), 2, N, 0)
+    pos, mot = model(t(g["state"]), t(g["attrs"]), empty, None, t(g["p_instance"]), action=t(g["action"]),
+                     rope_physics_param=t(g["phys"]))
+    z = np.zeros((2, 1), np.int32)
+    ref_pos, ref_mot = ago.forward(weights, g["state"], g["attrs"], g["action"], g["p_instance"], g["phys"],
+                                   np.zeros(2, np.int32), z, z)
+    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_TIGHT
+
+
+def test_forward_is_batch_composition_independent(weights, model):
+    """Sample b's output does not depend on what else is in the batch or where it sits (rows are independent;
+    the MFMA chain per row is identical) -> bitwise equality between B=1 and a slot inside B=7."""
+    g = synth.make_graph_inputs("rope", 300, 7, seed=8, spacing=0.1)
+    kw = dict(rope_physics_param=t(g["phys"]))
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    pos7, mot7 = model(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), action=t(g["action"]), **kw)
+    b = 4
+    one = {k: g[k][b:b + 1] for k in ("state", "attrs", "action", "p_instance", "phys", "mask", "tool_mask")}
+    csr1 = aggraph.build_edges(t(one["state"][:, -1]), 0.5, t(one["mask"]), t(one["tool_mask"]), 10, False, "batch", max_tools=1)
+    pos1, mot1 = model(t(one["state"]), t(one["attrs"]), csr1, None, t(one["p_instance"]), action=t(one["action"]),
+                       rope_physics_param=t(one["phys"]))
+    assert torch.equal(mot7[b], mot1[0]) and torch.equal(pos7[b], pos1[0])
+
+
+def test_forward_translation_invariance(model):
+    """Positions enter only through differences (model.py:168-173 skipped, :250): shifting the cloud by a
+    power-of-two offset (exact in fp32 at this magnitude) leaves pred_motion unchanged to rounding."""
+    g = synth.make_graph_inputs("rope", 200, 2, seed=2, spacing=0.1)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    args = (t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
+    _, m0 = model(t(g["state"]), *args, **kw)
+    shift = torch.tensor([4.0, -2.0, 8.0], device=DEV)
+    p1, m1 = model(t(g["state"]) + shift, *args, **kw)
+    assert (m0 - m1).abs().max().item() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------ rollout drivers
+def _ppm(material):
+    ppm = configs.ppm_optimizer_stub(material)
+    ppm.physics_param = {material: torch.tensor([0.5], device=DEV)}
+    return ppm
+
+
+@pytest.mark.parametrize("name", golden_files("dyn_"))
+def test_dynamics_golden(name, weights):
+    g = load_golden(name)
+    material = str(g["material"])
+    m = make_model(weights, material)
+    out = dynamics(t(g["state"]), t(g["action"]), m, DEV, _ppm(material))
+    assert out["state_seqs"].shape == g["state_seqs"].shape
+    assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
+    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= TOL_FWD
+
+
+@pytest.mark.parametrize("name", golden_files("dynmask_"))
+def test_dynamics_masked_golden(name, weights):
+    g = load_golden(name)
+    material = str(g["material"])
+    m = make_model(weights, material)
+    out = dynamics_masked(t(g["state_init"]), t(g["state_mask"]), t(g["action"]), m, DEV, _ppm(material))
+    assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
+    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= TOL_FWD
+
+
+def test_dynamics_vs_oracle_rope300(weights):
+    state, act = synth.make_mpc_inputs("rope", 300, 5, seed=12, len_lo=2, len_hi=5, spacing=0.1)
+    seq_ref, dec_ref = ago.dynamics(weights, configs.task_config("rope"), state, act)
+    m = make_model(weights, "rope")
+    out = dynamics(t(state), t(act), m, DEV, _ppm("rope"))
+    assert np.abs(out["state_seqs"].cpu().numpy() - seq_ref).max() <= TOL_FWD
+
+
+def test_rollout_full_size_matches_small_batch(weights, model):
+    """BASELINE configs[1] shape (rope ~1k particles, batch 256, 10 steps): sample b of the big batch must be
+    bit-identical to the same sample rolled out alone (size-independent property; the oracle would need minutes)."""
+    B, T = 256, 10
+    state, act = synth.make_mpc_inputs("rope", 1000, B, seed=3, len_lo=T, len_hi=T + 0.9, spacing=0.1)
+    ppm = _ppm("rope")
+    out = dynamics(t(state), t(act), model, DEV, ppm)["state_seqs"]
+    assert out.shape == (B, 1, 1000, 3) and torch.isfinite(out).all()
+    for b in (0, 131, 255):
+        one = dynamics(t(state), t(act[b:b + 1]), model, DEV, ppm)["state_seqs"]
+        assert torch.equal(out[b], one[0])
+    assert (out[:, 0] - t(state)[None]).abs().max().item() > 1e-3      # the rope actually moved
+
+
+def test_rollout_zero_steps_and_unreached_repeat(weights, model):
+    g = synth.make_graph_inputs("rope", 50, 3, seed=5, spacing=0.1)
+    thr = aggraph.threshold_sq(0.5, 3, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    rep = torch.tensor([2, 0, 7], dtype=torch.int32, device=DEV)       # 0: never recorded; 7 > n_steps: never reached
+    seq, fin = rollout(model, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]),
+                       t(g["mask"]), t(g["tool_mask"]), thr, rep, 3, 10, False, 1, return_state=True)
+    assert seq[1].abs().sum() == 0 and seq[2].abs().sum() == 0 and seq[0].abs().sum() > 0
+    # history shift: after 3 steps with n_his = 4 the oldest kept frame is the original newest frame
+    assert torch.equal(fin[:, 0], t(g["state"])[:, 3]) and torch.isfinite(fin).all()
+    seq0 = rollout(model, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]),
+                   t(g["mask"]), t(g["tool_mask"]), thr, rep, 0, 10, False, 1)
+    assert seq0.abs().sum() == 0

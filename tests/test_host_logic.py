@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference interface, exercised on CPU (no kernels run here)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_files, load_golden
+from adaptigraph_amd import _lib, configs, dist as agdist
+from adaptigraph_amd.graph import threshold_sq, csr_from_dense
+from adaptigraph_amd.model import DynamicsPredictor, STATE_DICT_KEYS
+from adaptigraph_amd.plan_utils import decode_action
+
+
+@pytest.mark.parametrize("name", golden_files("decode_action"))
+def test_decode_action_matches_reference(name):
+    g = load_golden(name)
+    d, r = decode_action(torch.from_numpy(g["action"]), push_length=float(g["push_length"]))
+    assert r.dtype == torch.int32 and np.array_equal(r.numpy(), g["repeat"])
+    assert np.abs(d.numpy() - g["decoded"]).max() <= 1e-6
+
+
+def test_threshold_rounding_per_variant():
+    dev = torch.device("cpu")
+    # 0.4: fp32(0.4)^2 and fp32(0.4^2 in double) differ by one ulp
+    single = threshold_sq(0.4, 2, dev, _lib.AG_VARIANT_SINGLE)
+    batch = threshold_sq(0.4, 2, dev, _lib.AG_VARIANT_BATCH)
+    assert single[0].item() == float(np.float32(0.4 * 0.4))
+    assert batch[0].item() == float(np.float32(0.4) * np.float32(0.4))
+    assert single[0].item() != batch[0].item()
+    per = threshold_sq(torch.tensor([0.3, 0.5]), 2, dev, _lib.AG_VARIANT_BATCH)
+    assert torch.equal(per, torch.tensor([0.3, 0.5]) ** 2)
+
+
+def test_state_dict_layout_is_the_reference_checkpoint_layout(weights):
+    m = DynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), "cpu")
+    sd = m.state_dict()
+    assert list(sd.keys()) == STATE_DICT_KEYS == list(weights.keys())
+    assert sum(v.numel() for v in sd.values()) == 252903
+    for k in STATE_DICT_KEYS:
+        assert tuple(sd[k].shape) == weights[k].shape
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})     # strict
+    assert torch.equal(m.relation_propagator.linear.weight, torch.from_numpy(weights["relation_propagator.linear.weight"]))
+
+
+def test_unsupported_configs_raise_like_the_reference():
+    mc = configs.model_config()
+    mc["offset_dim"] = 3
+    with pytest.raises(NotImplementedError):
+        DynamicsPredictor(mc, configs.material_config("rope"), configs.dataset_config("rope"), "cpu")
+    two = configs.material_config("rope")
+    two["material_index"]["cloth"] = 1
+    with pytest.raises(AssertionError):
+        DynamicsPredictor(configs.model_config(), two, configs.dataset_config("rope"), "cpu")
+
+
+def test_forward_refuses_cpu_tensors(weights):
+    m = DynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), "cpu")
+    g = load_golden("fwd_rope64")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.from_numpy(g["state"]), torch.from_numpy(g["attrs"]), None, None, torch.from_numpy(g["p_instance"]),
+          action=torch.from_numpy(g["action"]), rope_physics_param=torch.from_numpy(g["phys"]))
+
+
+def test_csr_from_dense_drops_padding_and_sorts_by_receiver():
+    N = 5
+    recv = [3, 0, 3, 1]
+    send = [1, 2, 4, 0]
+    Rr = torch.zeros(1, 7, N)
+    Rs = torch.zeros(1, 7, N)
+    for e, (r, s) in enumerate(zip(recv, send)):
+        Rr[0, e, r] = 1
+        Rs[0, e, s] = 1
+    csr = csr_from_dense(Rr, Rs)                 # 3 padded all-zero rows vanish (utils.py:127-137)
+    assert csr.row_ptr.tolist() == [0, 1, 2, 2, 4, 4]
+    assert csr.edge_recv[:4].tolist() == [0, 1, 3, 3]
+    assert csr.edge_send[:4].tolist() == [2, 0, 1, 4]          # stable within a receiver
+
+
+def test_shard_bounds_cover_the_batch():
+    for total, world in ((1024, 8), (10, 4), (3, 8), (256, 1)):
+        seen = []
+        for r in range(world):
+            lo, hi, per = agdist.shard_bounds(total, r, world)
+            assert hi - lo <= per
+            seen += list(range(lo, hi))
+        assert seen == list(range(total))
+
+
+def _gloo_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        state = torch.arange(12, dtype=torch.float32).reshape(4, 3)
+        action = torch.arange(total * 2 * 4, dtype=torch.float32).reshape(total, 2, 4)
+        calls = []
+
+        def fake_dynamics(st, act, tag):      # stands in for the engine: result depends only on the sample's action
+            calls.append(act.shape[0])
+            seq = act.sum(-1)[:, :, None, None] + st[None, None]
+            return {"state_seqs": seq, "action_seqs": act * 2}
+
+        out = agdist.dynamics_sharded(fake_dynamics, state, action, "x")
+        full = fake_dynamics(state, action, "x")
+        ok = all(torch.equal(out[k], full[k]) for k in full) and calls[0] <= (total + world - 1) // world
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_dynamics_sharded_gloo_world2(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000 + total
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
