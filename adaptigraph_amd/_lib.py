@@ -56,6 +56,10 @@ def lib():
         raise RuntimeError(
             f"adaptigraph_amd: {LIB_PATH} is missing. The engine has no CPU fallback; build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, no GPU required).")
+    # Load torch (and with it torch's bundled libamdhip64.so.7) FIRST: device pointers, streams and events are
+    # shared with torch, so both must sit on ONE HIP runtime instance; the loader then binds our DT_NEEDED
+    # libamdhip64.so.7 to the already-loaded copy.  (Loaded the other way round, torch finds no device.)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
