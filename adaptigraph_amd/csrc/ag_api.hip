@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -53,10 +54,16 @@ enum { W_PE0, B_PE0, W_PE1, B_PE1, W_PE2, B_PE2, W_RE0, B_RE0, W_RE1, B_RE1, W_R
 
 // Append one layer as n_tiles chunk images: 32 out-features x AG_WSTRIDE floats, columns [col0, col0+K) of W
 // in image columns [0, K), the bias (if any) in image column K, XOR-swizzled per ag_common.h.
+int g_layout = 0;   // 0: swizzled row image (LDS path); 1: fragment-major quads (L2-direct path)
+
 void pack_layer(std::vector<float> &dst, const float *W, int ld, int col0, int K, int n_out, const float *bias,
                 int n_tiles)
 {
-    auto at = [](int i, int k) { return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3); };
+    auto at = [](int i, int k) {
+        if (g_layout == 0) return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3);
+        const int m = k >> 3, h = (k >> 2) & 1, p = k & 3;     // quad m = 4t + q, half h, element p
+        return (m * 64 + h * 32 + i) * 4 + p;
+    };
     for (int ti = 0; ti < n_tiles; ++ti) {
         const size_t base = dst.size();
         dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
@@ -78,6 +85,7 @@ struct ag_model {
     size_t dev_floats = 0;
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
+    int mlp_variant = 0, prio = 0;   // kernel variant knobs (env AG_MLP_VARIANT / AG_MLP_PRIO at create time)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
     size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -91,7 +99,10 @@ int pack_and_upload(ag_model *m, const float *const *t)
     const int F = m->cfg.nf, dn = m->cfg.attr_dim + m->cfg.phys_dim + m->cfg.action_dim;
     const int de = 2 * m->cfg.attr_dim + 1 + 3 * m->cfg.n_his;
     std::vector<float> s;
-    s.reserve((size_t)81 * AG_CHUNK_FLOATS);
+    s.reserve((size_t)2 * 81 * AG_CHUNK_FLOATS);
+    size_t offs[2][4];
+    for (int layout = 0; layout < 2; ++layout) {
+    g_layout = layout;
     const size_t o_node = s.size();
     pack_layer(s, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
     pack_layer(s, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
@@ -113,15 +124,17 @@ int pack_and_upload(ag_model *m, const float *const *t)
     pack_layer(s, t[W_D0], F, 0, F, F, t[B_D0], AG_NT);
     pack_layer(s, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
     pack_layer(s, t[W_D2], F, 0, F, 3, t[B_D2], 1);
+    offs[layout][0] = o_node; offs[layout][1] = o_edge; offs[layout][2] = o_mid; offs[layout][3] = o_last;
+    }
+    g_layout = 0;
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
-    m->w.node_encode = reinterpret_cast<const float4 *>(m->dev + o_node);
-    m->w.edge_encode = reinterpret_cast<const float4 *>(m->dev + o_edge);
-    m->w.node_mid = reinterpret_cast<const float4 *>(m->dev + o_mid);
-    m->w.node_last = reinterpret_cast<const float4 *>(m->dev + o_last);
+    auto at = [&](int layout, int k) { return reinterpret_cast<const float4 *>(m->dev + offs[layout][k]); };
+    m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
+    m->w.node_encode_l2 = at(1, 0); m->w.edge_encode_l2 = at(1, 1); m->w.node_mid_l2 = at(1, 2); m->w.node_last_l2 = at(1, 3);
     return AG_OK;
 }
 
@@ -187,6 +200,8 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
 void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
+    a.mlp_variant = m->mlp_variant;
+    a.prio = m->prio;
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
     for (int p = 0; p < a.pstep; ++p) {
@@ -217,6 +232,8 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
         if (!weights[i]) return fail(AG_ERR_ARG, "ag_model_create: weight %d is null", i);
     ag_model *m = new ag_model();
     m->cfg = *cfg;
+    if (const char *v = getenv("AG_MLP_VARIANT")) m->mlp_variant = atoi(v);
+    if (const char *v = getenv("AG_MLP_PRIO")) m->prio = atoi(v);
     const int rc = pack_and_upload(m, weights);
     if (rc != AG_OK) {
         if (m->dev) (void)hipFree(m->dev);

@@ -24,22 +24,38 @@
 #include "ag_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 is a union-y struct that defeats SROA)
 
 namespace {
+
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
 struct ChunkPipe {
     const float4 *g;   // weight stream (global), chunk c at g + c*AG_CHUNK_F4
     int c;             // chunk currently resident in LDS buffer (c & 1)
     int total;
     float *lds;        // 2 * AG_CHUNK_FLOATS
+    v4f pf0, pf1, pf2, pf3, pf4;      // chunk c+1 in flight (global -> registers), written to LDS mid-tile
 };
+
+__device__ __forceinline__ void pipe_fetch(ChunkPipe &P, int chunk)
+{
+    const int cn = chunk < P.total ? chunk : P.total - 1;   // past the end: re-fetch the last chunk (harmless)
+    const v4f *g = reinterpret_cast<const v4f *>(P.g + (size_t)cn * AG_CHUNK_F4 + threadIdx.x);
+    P.pf0 = g[0]; P.pf1 = g[256]; P.pf2 = g[512]; P.pf3 = g[768]; P.pf4 = g[1024];
+}
+
+__device__ __forceinline__ void pipe_commit(ChunkPipe &P, int buf)
+{
+    v4f *d = reinterpret_cast<v4f *>(P.lds + buf * AG_CHUNK_FLOATS) + threadIdx.x;
+    d[0] = P.pf0; d[256] = P.pf1; d[512] = P.pf2; d[768] = P.pf3; d[1024] = P.pf4;
+}
 
 __device__ __forceinline__ void pipe_start(ChunkPipe &P)
 {
-    const int tid = threadIdx.x;
-    float4 *d = reinterpret_cast<float4 *>(P.lds);
-#pragma unroll
-    for (int u = 0; u < 5; ++u) d[tid + 256 * u] = P.g[tid + 256 * u];
+    pipe_fetch(P, 0);
+    pipe_commit(P, 0);
+    pipe_fetch(P, 1);
     __syncthreads();
 }
 
@@ -73,12 +89,16 @@ struct ResidInit {  // accumulator := Pn + h (packed tables), i.e. W_pp[:, :F].e
 // K = number of input columns visited (k >= K is zero padding).  With BIAS the layer's bias is column K of the
 // packed weights and the matching activation "feature K" is forced to 1.0 here, so the bias rides the MFMA chain
 // (columns >= AG_F of every activation table are padding, nothing else reads them).
+// Weight pipeline per tile: [first half of the MFMAs] -> commit chunk c+1 (fetched half a tile ago) to the idle
+// LDS buffer and fetch chunk c+2 into the same registers -> [second half] -> one barrier.  The barrier is the
+// only thing between two tiles; no global or LDS-store latency sits on that path.
 template <int K, int NT, bool RELU, bool BIAS, class Init>
 __device__ __forceinline__ void dense_layer(ChunkPipe &P, const f32x16 (&in)[(K + 32) / 32], f32x16 (&out)[NT],
                                             const Init &init)
 {
     constexpr int KE = K + (BIAS ? 1 : 0);
-    constexpr int KT = (K + 32) / 32;
+    constexpr int PT = (KE + 7) / 8;      // quads (= 4 k-steps = one ds_read_b128 per lane) per tile
+    constexpr int MID = PT / 2;
     const int tid = threadIdx.x;
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
     // per-lane fragment addresses: row i, 16-byte column (8t + 2q + h) ^ ((i >> 1) & 7)  (host pre-swizzles the
@@ -90,42 +110,111 @@ __device__ __forceinline__ void dense_layer(ChunkPipe &P, const f32x16 (&in)[(K 
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti) {
         const float *buf = P.lds + (P.c & 1) * AG_CHUNK_FLOATS;
-        // next chunk: issue the loads before the MFMA block, they land under it (last chunk re-fetches itself)
-        const int cn = P.c + 1 < P.total ? P.c + 1 : P.c;
-        const float4 *g = P.g + (size_t)cn * AG_CHUNK_F4 + tid;
-        const float4 pf0 = g[0], pf1 = g[256], pf2 = g[512], pf3 = g[768], pf4 = g[1024];
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA block (hipcc otherwise sinks it to the stores)
         f32x16 acc = init(ti);
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
+        for (int m = 0; m < PT; ++m) {
+            const int t = m / 4, q = m % 4;
+            if (m == MID) {
+                __builtin_amdgcn_sched_barrier(0);
+                pipe_commit(P, (P.c + 1) & 1);
+                pipe_fetch(P, P.c + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float4 w = *reinterpret_cast<const float4 *>(buf + qoff[q] + 32 * t);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (32 * t + 8 * q < KE) {
-                    const float4 w = *reinterpret_cast<const float4 *>(buf + qoff[q] + 32 * t);
-                    const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int k0 = 32 * t + 8 * q + p;        // column seen by the h = 0 half (h = 1: k0 + 4)
-                        if (k0 < KE) {
-                            float x = in[t][4 * q + p];
-                            if (BIAS && (k0 == K || k0 + 4 == K)) x = (h == (k0 == K ? 0 : 1)) ? 1.0f : x;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], x, acc, 0, 0, 0);
-                        }
-                    }
+            for (int p = 0; p < 4; ++p) {
+                const int k0 = 32 * t + 8 * q + p;        // column seen by the h = 0 half (h = 1: k0 + 4)
+                if (k0 < KE) {
+                    float x = in[t][4 * q + p];
+                    if (BIAS && (k0 == K || k0 + 4 == K)) x = (h == (k0 == K ? 0 : 1)) ? 1.0f : x;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], x, acc, 0, 0, 0);
                 }
             }
         }
         if (RELU) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
         }
         out[ti] = acc;
-        float4 *d = reinterpret_cast<float4 *>(P.lds + ((P.c + 1) & 1) * AG_CHUNK_FLOATS) + tid;
-        d[0] = pf0; d[256] = pf1; d[512] = pf2; d[768] = pf3; d[1024] = pf4;
         __syncthreads();
         ++P.c;
     }
 }
+
+// ---- variant 1: weights straight from L2 (no LDS, no barriers) -------------------------------------------
+// The stream is repacked "fragment-major": chunk (out-tile) c, quad m = 4t + q holds, for lane l = (i, h),
+// the 4 floats W[32c' + i][32t + 8q + 4h .. +3] at float4 index c*1280 + m*64 + l, so one wave-wide
+// global_load_dwordx4 moves a fully coalesced 1 KiB fragment block = the A operands of 4 MFMAs.
+// Weights (1.7 MB) are L2-resident; a register ring of D quads keeps D loads in flight ahead of the MFMAs.
+// Waves never synchronise, so a stalled wave never holds up its workgroup.
+template <int K, int NT, bool RELU, bool BIAS, int D, class Init>
+__device__ __forceinline__ void dense_layer_l2(const float4 *__restrict__ gs, int &c, const f32x16 (&in)[(K + 32) / 32],
+                                               f32x16 (&out)[NT], const Init &init)
+{
+    constexpr int KE = K + (BIAS ? 1 : 0);
+    constexpr int PT = (KE + 7) / 8;          // quads per out-tile that touch columns < KE
+    constexpr int NQ = PT * NT;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const float4 *base = gs + (size_t)c * AG_CHUNK_F4 + lane;
+    float4 ring[D];
+#pragma unroll
+    for (int n = 0; n < D && n < NQ; ++n) ring[n] = base[((n / PT) * 20 + (n % PT)) * 64];
+    f32x16 acc;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int ti = n / PT, m = n % PT, t = m / 4, q = m % 4;
+        if (m == 0) acc = init(ti);
+        const float4 w = ring[n % D];
+        if (n + D < NQ) ring[n % D] = base[(((n + D) / PT) * 20 + ((n + D) % PT)) * 64];
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int k0 = 32 * t + 8 * q + p;
+            if (k0 < KE) {
+                float x = in[t][4 * q + p];
+                if (BIAS && (k0 == K || k0 + 4 == K)) x = (h == (k0 == K ? 0 : 1)) ? 1.0f : x;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], x, acc, 0, 0, 0);
+            }
+        }
+        if (m == PT - 1) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            }
+            out[ti] = acc;
+        }
+    }
+    c += NT;
+}
+
+// Policy object so the kernels are written once for both weight paths.
+template <int V> struct Net;
+template <> struct Net<0> {
+    ChunkPipe P;
+    __device__ __forceinline__ Net(const float4 *lds_stream, const float4 * /*l2_stream*/, int total, float *lds)
+        : P{lds_stream, 0, total, lds, v4f(0.f), v4f(0.f), v4f(0.f), v4f(0.f), v4f(0.f)} { pipe_start(P); }
+    template <int K, int NT, bool RELU, bool BIAS, class Init>
+    __device__ __forceinline__ void layer(const f32x16 (&in)[(K + 32) / 32], f32x16 (&out)[NT], const Init &init)
+    {
+        dense_layer<K, NT, RELU, BIAS>(P, in, out, init);
+    }
+};
+template <> struct Net<1> {
+    const float4 *g;
+    int c;
+    __device__ __forceinline__ Net(const float4 * /*lds_stream*/, const float4 *l2_stream, int /*total*/, float * /*lds*/)
+        : g(l2_stream), c(0) {}
+    template <int K, int NT, bool RELU, bool BIAS, class Init>
+    __device__ __forceinline__ void layer(const f32x16 (&in)[(K + 32) / 32], f32x16 (&out)[NT], const Init &init)
+    {
+        dense_layer_l2<K, NT, RELU, BIAS, 6>(g, c, in, out, init);
+    }
+};
+
+#define AG_LDS_DECL(V)                                                                     \
+    __shared__ __attribute__((aligned(16))) float lds_[(V) == 0 ? 2 * AG_CHUNK_FLOATS : 4]; \
+    float *lds = lds_;
 
 // ---- register image <-> HBM movers ------------------------------------------------------------
 __device__ __forceinline__ void store_rowmajor(float *row, const f32x16 (&v)[AG_NT], int h, bool valid)
@@ -176,9 +265,11 @@ __device__ __forceinline__ void copy_tiles(f32x16 (&dst)[N], const f32x16 (&src)
 //   Hr  = W_rp[:, F:2F] . h0,  Hs = W_rp[:, 2F:3F] . h0   (receiver / sender column blocks of
 //          relation_propagator applied at NODE level instead of per edge, model.py:283-289)
 // ---------------------------------------------------------------------------------------------
+template <int V>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS];
+    AG_LDS_DECL(V)
+    if (a.prio && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int g = blockIdx.x * AG_ROWS_PER_BLOCK + wave * 32 + j;
@@ -203,19 +294,18 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
             in0[0][p] = v;
         }
     }
-    ChunkPipe P{w.node_encode, 0, 30, lds};
-    pipe_start(P);
+    Net<V> net(w.node_encode, w.node_encode_l2, 30, lds);
     f32x16 x[AG_NT], y[AG_NT];
-    dense_layer<AG_NODE_IN_MAX - 1, AG_NT, true, false>(P, in0, x, ZeroInit{});
-    dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});
-    dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{});   // x = particle_encode = h0
+    net.template layer<AG_NODE_IN_MAX - 1, AG_NT, true, false>(in0, x, ZeroInit{});
+    net.template layer<AG_F, AG_NT, true, true>(x, y, ZeroInit{});
+    net.template layer<AG_F, AG_NT, true, true>(y, x, ZeroInit{});   // x = particle_encode = h0
     const size_t blk = (size_t)(blockIdx.x * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
     store_packed(a.h + blk, x);
-    dense_layer<AG_F, AG_NT, false, true>(P, x, y, ZeroInit{});  // Pn
+    net.template layer<AG_F, AG_NT, false, true>(x, y, ZeroInit{});  // Pn
     store_packed(a.pn + blk, y);
-    dense_layer<AG_F, AG_NT, false, false>(P, x, y, ZeroInit{});  // Hr
+    net.template layer<AG_F, AG_NT, false, false>(x, y, ZeroInit{});  // Hr
     store_rowmajor(a.hr + (size_t)gc * AG_FP, y, h, valid);
-    dense_layer<AG_F, AG_NT, false, false>(P, x, y, ZeroInit{});  // Hs
+    net.template layer<AG_F, AG_NT, false, false>(x, y, ZeroInit{});  // Hs
     store_rowmajor(a.hs + (size_t)gc * AG_FP, y, h, valid);
 }
 
@@ -226,9 +316,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
 //   Eterm      = W_rp[:, :F] . enc_e + b_rp      (first column block of relation_propagator, model.py:289)
 // The one-hot gathers Rr.bmm / Rs.bmm become indexed reads of the (L2-resident) raw node inputs.
 // ---------------------------------------------------------------------------------------------
+template <int V>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS];
+    AG_LDS_DECL(V)
+    if (a.prio && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int E = a.row_ptr[Mn];
@@ -279,13 +371,12 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 #pragma unroll
         for (int p = 0; p < 4; ++p) in0[0][4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
 
-    ChunkPipe P{w.edge_encode, 0, 20, lds};
-    pipe_start(P);
+    Net<V> net(w.edge_encode, w.edge_encode_l2, 20, lds);
     f32x16 x[AG_NT], y[AG_NT];
-    dense_layer<AG_EDGE_IN + 1, AG_NT, true, false>(P, in0, x, ZeroInit{});
-    dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});
-    dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{});    // relation_encode
-    dense_layer<AG_F, AG_NT, false, true>(P, x, y, ZeroInit{});   // Eterm
+    net.template layer<AG_EDGE_IN + 1, AG_NT, true, false>(in0, x, ZeroInit{});
+    net.template layer<AG_F, AG_NT, true, true>(x, y, ZeroInit{});
+    net.template layer<AG_F, AG_NT, true, true>(y, x, ZeroInit{});    // relation_encode
+    net.template layer<AG_F, AG_NT, false, true>(x, y, ZeroInit{});   // Eterm
     store_rowmajor(a.eterm + (size_t)(valid ? e : 0) * AG_FP, y, h, valid);
 }
 
@@ -293,10 +384,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 // Node update for one propagation step (model.py:299-301), then either the next step's node-level
 // relation terms (Hr, Hs) or — after the last step — the decoder + clamp + integrate (model.py:306-309).
 // ---------------------------------------------------------------------------------------------
-template <bool LAST>
+template <bool LAST, int V>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS];
+    AG_LDS_DECL(V)
+    if (a.prio && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int g = blockIdx.x * AG_ROWS_PER_BLOCK + wave * 32 + j;
@@ -305,21 +397,20 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
 
     f32x16 x[AG_NT], y[AG_NT];
     load_rowmajor(a.agg + (size_t)gc * AG_FP, x, h);
-    ChunkPipe P{LAST ? w.node_last : w.node_mid, 0, LAST ? 16 : 15, lds};
-    pipe_start(P);
+    Net<V> net(LAST ? w.node_last : w.node_mid, LAST ? w.node_last_l2 : w.node_mid_l2, LAST ? 16 : 15, lds);
     const size_t blk = (size_t)(blockIdx.x * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
-    dense_layer<AG_F, AG_NT, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
+    net.template layer<AG_F, AG_NT, true, false>(x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
     if (!LAST) {
         store_packed(a.h + blk, y);
-        dense_layer<AG_F, AG_NT, false, false>(P, y, x, ZeroInit{});
+        net.template layer<AG_F, AG_NT, false, false>(y, x, ZeroInit{});
         store_rowmajor(a.hr + (size_t)gc * AG_FP, x, h, valid);
-        dense_layer<AG_F, AG_NT, false, false>(P, y, x, ZeroInit{});
+        net.template layer<AG_F, AG_NT, false, false>(y, x, ZeroInit{});
         store_rowmajor(a.hs + (size_t)gc * AG_FP, x, h, valid);
     } else {
-        dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
-        dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
+        net.template layer<AG_F, AG_NT, true, true>(y, x, ZeroInit{});    // linear_0 + ReLU
+        net.template layer<AG_F, AG_NT, true, true>(x, y, ZeroInit{});    // linear_1 + ReLU
         f32x16 m[1];
-        dense_layer<AG_F, 1, false, true>(P, y, m, ZeroInit{});       // linear_2 -> rows 0..2 of tile 0
+        net.template layer<AG_F, 1, false, true>(y, m, ZeroInit{});       // linear_2 -> rows 0..2 of tile 0
         const int b = gc / a.N, i = gc - b * a.N;
         if (valid && h == 0 && i < a.n_p) {
             const float *cur = a.state + (((size_t)b * AG_NHIS + (AG_NHIS - 1)) * a.N + i) * 3;
@@ -339,21 +430,30 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
 
 static inline int blocks_for(int rows) { return (rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK; }
 
-void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
-{
-    hipLaunchKernelGGL(node_encode_kernel, dim3(blocks_for(a.B * a.N)), dim3(AG_MLP_THREADS), 0, s, w, a);
-}
+#define AG_LAUNCH(KERNEL, rows)                                                                          \
+    do {                                                                                                 \
+        if (a.mlp_variant == 1)                                                                          \
+            hipLaunchKernelGGL((KERNEL<1>), dim3(blocks_for(rows)), dim3(AG_MLP_THREADS), 0, s, w, a);   \
+        else                                                                                             \
+            hipLaunchKernelGGL((KERNEL<0>), dim3(blocks_for(rows)), dim3(AG_MLP_THREADS), 0, s, w, a);   \
+    } while (0)
+
+void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s) { AG_LAUNCH(node_encode_kernel, a.B * a.N); }
 
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
-    hipLaunchKernelGGL(edge_encode_kernel, dim3(blocks_for(a.e_cap)), dim3(AG_MLP_THREADS), 0, s, w, a);
+    AG_LAUNCH(edge_encode_kernel, a.e_cap);
 }
 
 void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hipStream_t s)
 {
-    if (last)
-        hipLaunchKernelGGL(node_update_kernel<true>, dim3(blocks_for(a.B * a.N)), dim3(AG_MLP_THREADS), 0, s, w, a);
-    else
-        hipLaunchKernelGGL(node_update_kernel<false>, dim3(blocks_for(a.B * a.N)), dim3(AG_MLP_THREADS), 0, s, w, a);
+    const dim3 grid(blocks_for(a.B * a.N)), block(AG_MLP_THREADS);
+    if (last) {
+        if (a.mlp_variant == 1) hipLaunchKernelGGL((node_update_kernel<true, 1>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<true, 0>), grid, block, 0, s, w, a);
+    } else {
+        if (a.mlp_variant == 1) hipLaunchKernelGGL((node_update_kernel<false, 1>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<false, 0>), grid, block, 0, s, w, a);
+    }
 }
