@@ -54,16 +54,10 @@ enum { W_PE0, B_PE0, W_PE1, B_PE1, W_PE2, B_PE2, W_RE0, B_RE0, W_RE1, B_RE1, W_R
 
 // Append one layer as n_tiles chunk images: 32 out-features x AG_WSTRIDE floats, columns [col0, col0+K) of W
 // in image columns [0, K), the bias (if any) in image column K, XOR-swizzled per ag_common.h.
-int g_layout = 0;   // 0: swizzled row image (LDS path); 1: fragment-major quads (L2-direct path)
-
 void pack_layer(std::vector<float> &dst, const float *W, int ld, int col0, int K, int n_out, const float *bias,
                 int n_tiles)
 {
-    auto at = [](int i, int k) {
-        if (g_layout == 0) return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3);
-        const int m = k >> 3, h = (k >> 2) & 1, p = k & 3;     // quad m = 4t + q, half h, element p
-        return (m * 64 + h * 32 + i) * 4 + p;
-    };
+    auto at = [](int i, int k) { return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3); };
     for (int ti = 0; ti < n_tiles; ++ti) {
         const size_t base = dst.size();
         dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
@@ -85,7 +79,11 @@ struct ag_model {
     size_t dev_floats = 0;
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
-    int mlp_variant = 0, prio = 0;   // kernel variant knobs (env AG_MLP_VARIANT / AG_MLP_PRIO at create time)
+    int fuse_agg = 1;           // env AG_FUSE_AGG=0 keeps the standalone aggregate kernel (A/B knob)
+    int max_blocks = 512;       // persistent grid: 2 workgroups per CU
+    int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
+    hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
     size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -99,10 +97,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
     const int F = m->cfg.nf, dn = m->cfg.attr_dim + m->cfg.phys_dim + m->cfg.action_dim;
     const int de = 2 * m->cfg.attr_dim + 1 + 3 * m->cfg.n_his;
     std::vector<float> s;
-    s.reserve((size_t)2 * 81 * AG_CHUNK_FLOATS);
-    size_t offs[2][4];
-    for (int layout = 0; layout < 2; ++layout) {
-    g_layout = layout;
+    s.reserve((size_t)81 * AG_CHUNK_FLOATS);
     const size_t o_node = s.size();
     pack_layer(s, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
     pack_layer(s, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
@@ -124,17 +119,15 @@ int pack_and_upload(ag_model *m, const float *const *t)
     pack_layer(s, t[W_D0], F, 0, F, F, t[B_D0], AG_NT);
     pack_layer(s, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
     pack_layer(s, t[W_D2], F, 0, F, 3, t[B_D2], 1);
-    offs[layout][0] = o_node; offs[layout][1] = o_edge; offs[layout][2] = o_mid; offs[layout][3] = o_last;
-    }
-    g_layout = 0;
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
-    auto at = [&](int layout, int k) { return reinterpret_cast<const float4 *>(m->dev + offs[layout][k]); };
-    m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
-    m->w.node_encode_l2 = at(1, 0); m->w.edge_encode_l2 = at(1, 1); m->w.node_mid_l2 = at(1, 2); m->w.node_last_l2 = at(1, 3);
+    m->w.node_encode = reinterpret_cast<const float4 *>(m->dev + o_node);
+    m->w.edge_encode = reinterpret_cast<const float4 *>(m->dev + o_edge);
+    m->w.node_mid = reinterpret_cast<const float4 *>(m->dev + o_mid);
+    m->w.node_last = reinterpret_cast<const float4 *>(m->dev + o_last);
     return AG_OK;
 }
 
@@ -157,6 +150,8 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
     a.pn = c.take<float>(L.rows_pad * AG_FP);
     a.hr = c.take<float>(L.rows_pad * AG_FP);
     a.hs = c.take<float>(L.rows_pad * AG_FP);
+    a.hr_out = c.take<float>(L.rows_pad * AG_FP);
+    a.hs_out = c.take<float>(L.rows_pad * AG_FP);
     a.agg = c.take<float>(L.rows_pad * AG_FP);
     a.eterm = c.take<float>(L.e_pad * AG_FP);
 }
@@ -200,13 +195,15 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
 void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
-    a.mlp_variant = m->mlp_variant;
-    a.prio = m->prio;
+    a.fuse_agg = m->fuse_agg;
+    a.max_blocks = m->max_blocks;
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
     for (int p = 0; p < a.pstep; ++p) {
-        { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(a, s); }
+        if (!a.fuse_agg) { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(a, s); }
         { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, a, p == a.pstep - 1, s); }
+        std::swap(a.hr, a.hr_out);
+        std::swap(a.hs, a.hs_out);
     }
 }
 
@@ -232,8 +229,15 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
         if (!weights[i]) return fail(AG_ERR_ARG, "ag_model_create: weight %d is null", i);
     ag_model *m = new ag_model();
     m->cfg = *cfg;
-    if (const char *v = getenv("AG_MLP_VARIANT")) m->mlp_variant = atoi(v);
-    if (const char *v = getenv("AG_MLP_PRIO")) m->prio = atoi(v);
+    if (const char *v = getenv("AG_FUSE_AGG")) m->fuse_agg = atoi(v);
+    if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            m->max_blocks = 2 * prop.multiProcessorCount;
+        if (const char *v = getenv("AG_MAX_BLOCKS")) m->max_blocks = atoi(v);
+    }
     const int rc = pack_and_upload(m, weights);
     if (rc != AG_OK) {
         if (m->dev) (void)hipFree(m->dev);
@@ -256,8 +260,23 @@ int ag_model_destroy(ag_model *m)
     for (auto &v : m->ev)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (m->edge_counter) (void)hipFree(m->edge_counter);
+    for (int k = 0; k < 4; ++k) {
+        if (m->aux_stream[k]) (void)hipStreamDestroy(m->aux_stream[k]);
+        if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->dev) (void)hipFree(m->dev);
     delete m;
+    return AG_OK;
+}
+
+int ag_set_option(ag_model *m, const char *name, int value)
+{
+    if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
+    if (!strcmp(name, "rollout_streams")) m->split = value;
+    else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
+    else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
+    else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }
 
@@ -369,33 +388,52 @@ int ag_forward(ag_model *m, const float *state, const float *attrs, const float 
     return AG_OK;
 }
 
-static void carve_rollout(Carver &c, const ag_rollout_params *p, AgFwdArgs &f, AgEdgeArgs &e, float **state,
+static void carve_rollout(Carver &c, const ag_rollout_params *p, int B, AgFwdArgs &f, AgEdgeArgs &e, float **state,
                           float **pred_pos, float **pred_motion, int n_his)
 {
-    const int64_t e_cap = ag_edge_capacity(p->B, p->N, p->topk, p->connect_tools_all, p->max_tools);
-    const size_t rows = (size_t)p->B * p->N;
+    const int64_t e_cap = ag_edge_capacity(B, p->N, p->topk, p->connect_tools_all, p->max_tools);
+    const size_t rows = (size_t)B * p->N;
     *state = c.take<float>(rows * n_his * 3);
-    *pred_pos = c.take<float>((size_t)p->B * p->n_p * 3 + 4);
-    *pred_motion = c.take<float>((size_t)p->B * p->n_p * 3 + 4);
+    *pred_pos = c.take<float>((size_t)B * p->n_p * 3 + 4);
+    *pred_motion = c.take<float>((size_t)B * p->n_p * 3 + 4);
     e.row_ptr = c.take<int32_t>(rows + 1);
     e.edge_recv = c.take<int32_t>((size_t)e_cap + 1);
     e.edge_send = c.take<int32_t>((size_t)e_cap + 1);
-    e.B = p->B; e.N = p->N; e.connect = p->connect_tools_all ? 1 : 0;
+    e.B = B; e.N = p->N; e.connect = p->connect_tools_all ? 1 : 0;
     edge_caps(p->N, p->topk, e.connect, p->max_tools, &e.cap0, &e.cap);
     carve_edges(c, e);
-    carve_forward(c, f, p->B, p->N, e_cap);
+    carve_forward(c, f, B, p->N, e_cap);
     f.e_cap = (int)e_cap;
+}
+
+// The batch is rolled out as up to AG_MAX_PARTS independent parts on separate streams: graphs never interact,
+// and co-running kernel streams de-phase the memory-bound stages (segment reduce, edge-feature gathers, edge
+// build) of one part against the MFMA-bound stages of another — each part's persistent kernels take an equal
+// share of the resident-workgroup slots.
+#define AG_MAX_PARTS 4
+static int rollout_parts(int B, int want)
+{
+    int parts = want < 1 ? 1 : (want > AG_MAX_PARTS ? AG_MAX_PARTS : want);
+    while (parts > 1 && B / parts < 8) --parts;
+    return parts;
+}
+static void part_range(int B, int parts, int k, int *b0, int *nb)
+{
+    const int per = (B + parts - 1) / parts;
+    *b0 = k * per < B ? k * per : B;
+    *nb = (*b0 + per <= B) ? per : B - *b0;
 }
 
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
 {
     if (!p) return 0;
+    // sized for the unsplit layout, which is the largest (per-part tables are rounded up separately, so add slack)
+    Carver c(nullptr, 0);
     AgFwdArgs f{};
     AgEdgeArgs e{};
     float *a, *b, *d;
-    Carver c(nullptr, 0);
-    carve_rollout(c, p, f, e, &a, &b, &d, AG_NHIS);
-    return align_up(c.off, 256);
+    carve_rollout(c, p, p->B, f, e, &a, &b, &d, AG_NHIS);
+    return align_up(c.off, 256) + (size_t)AG_MAX_PARTS * 64 * 1024 * 1024 / 16;
 }
 
 int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, const float *delta, const float *attrs,
@@ -409,40 +447,78 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
     if (p->height_mode == AG_HEIGHT_MASKED_MEAN && !obj_mask) return fail(AG_ERR_ARG, "ag_rollout: obj_mask is null");
     if (p->B < 1 || p->N < 1 || p->n_p < 1 || p->n_p > p->N || p->topk < 1 || p->topk > 64 || p->n_steps < 0)
         return fail(AG_ERR_ARG, "ag_rollout: bad sizes");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    AgFwdArgs f{};
-    AgEdgeArgs e{};
-    float *state, *pred_pos, *pred_motion;
+    if (m->cfg.phys_dim > 0 && !phys) return fail(AG_ERR_ARG, "ag_rollout: phys is null");
+    hipStream_t s0 = static_cast<hipStream_t>(stream);
+    const int H = m->cfg.n_his, N = p->N, n_p = p->n_p, Pd = m->cfg.phys_dim;
+    const int parts = rollout_parts(p->B, m->split);
+    for (int k = 1; k < parts; ++k)
+        if (!m->aux_stream[k]) {
+            AG_HIP(hipStreamCreateWithFlags(&m->aux_stream[k], hipStreamNonBlocking));
+            AG_HIP(hipEventCreateWithFlags(&m->ev_join[k], hipEventDisableTiming));
+        }
+    if (parts > 1 && !m->ev_fork) AG_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     Carver c(workspace, workspace_bytes);
-    carve_rollout(c, p, f, e, &state, &pred_pos, &pred_motion, m->cfg.n_his);
-    if (!c.ok()) return fail(AG_ERR_WS, "ag_rollout: workspace %zu < %zu bytes", workspace_bytes, c.off);
-    const size_t state_bytes = (size_t)p->B * m->cfg.n_his * p->N * 3 * sizeof(float);
-    AG_HIP(hipMemcpyAsync(state, state0, state_bytes, hipMemcpyDeviceToDevice, s));
-
-    e.mask = mask; e.tool = tool_mask; e.thr_sq = thr_sq; e.topk = p->topk; e.variant = AG_VARIANT_BATCH;
-    e.max_tools = p->max_tools;
-    f.state = state; f.attrs = attrs; f.action = delta; f.p_instance = p_instance; f.phys = phys;
-    f.row_ptr = e.row_ptr; f.edge_recv = e.edge_recv; f.edge_send = e.edge_send;
-    f.pred_pos = pred_pos; f.pred_motion = pred_motion;
-    f.B = p->B; f.N = p->N; f.n_p = p->n_p; f.n_inst = p->n_instance; f.phys_dim = m->cfg.phys_dim;
-    f.pstep = m->cfg.pstep; f.clamp = m->cfg.motion_clamp;
-
-    AgStepArgs st{};
-    st.state = state; st.delta = delta; st.pred_pos = pred_pos; st.obj_mask = obj_mask; st.repeat = repeat;
-    st.out_seq = out_seq; st.B = p->B; st.N = p->N; st.n_p = p->n_p; st.H = m->cfg.n_his;
-    st.height_mode = p->height_mode; st.raise = p->gripper_raise;
-
-    const size_t plane = (size_t)p->N * 3;
-    for (int ai = 1; ai <= p->n_steps; ++ai) {
-        // edges on the current frame = state[:, -1] (forward_dynamics.py:125 / :171)
-        e.pos = state + (size_t)(m->cfg.n_his - 1) * plane;
-        e.pos_stride = (size_t)m->cfg.n_his * plane;
-        { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(e, s); }
-        run_forward(m, f, s);
-        st.step = ai;
-        { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(st, s); }
+    struct Part { AgFwdArgs f{}; AgEdgeArgs e{}; float *state, *pp, *pm; int b0, B; } part[AG_MAX_PARTS];
+    for (int k = 0; k < parts; ++k) {
+        part_range(p->B, parts, k, &part[k].b0, &part[k].B);
+        carve_rollout(c, p, part[k].B, part[k].f, part[k].e, &part[k].state, &part[k].pp, &part[k].pm, H);
     }
-    if (state_final) AG_HIP(hipMemcpyAsync(state_final, state, state_bytes, hipMemcpyDeviceToDevice, s));
+    if (!c.ok()) return fail(AG_ERR_WS, "ag_rollout: workspace %zu < %zu bytes", workspace_bytes, c.off);
+    if (parts > 1) {
+        AG_HIP(hipEventRecord(m->ev_fork, s0));
+        for (int k = 1; k < parts; ++k) AG_HIP(hipStreamWaitEvent(m->aux_stream[k], m->ev_fork, 0));
+    }
+    const size_t plane = (size_t)N * 3;
+    const int saved_blocks = m->max_blocks;
+    m->max_blocks = saved_blocks / parts > 0 ? saved_blocks / parts : 1;
+    int rc = AG_OK;
+    // issue the steps round-robin over the parts so every stream always has work queued
+    struct Run { AgStepArgs st{}; hipStream_t s; } run[AG_MAX_PARTS];
+    for (int k = 0; k < parts && rc == AG_OK; ++k) {
+        Part &q = part[k];
+        hipStream_t s = k == 0 ? s0 : m->aux_stream[k];
+        run[k].s = s;
+        const size_t b0 = (size_t)q.b0;
+        const size_t state_bytes = (size_t)q.B * H * plane * sizeof(float);
+        if (hipMemcpyAsync(q.state, state0 + b0 * H * plane, state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = AG_ERR_HIP; break; }
+        AgEdgeArgs &e = q.e;
+        AgFwdArgs &f = q.f;
+        e.mask = mask + b0 * N; e.tool = tool_mask + b0 * N; e.thr_sq = thr_sq + b0; e.topk = p->topk;
+        e.variant = AG_VARIANT_BATCH; e.max_tools = p->max_tools;
+        e.pos = q.state + (size_t)(H - 1) * plane;     // edges on the current frame = state[:, -1] (forward_dynamics.py:125 / :171)
+        e.pos_stride = (size_t)H * plane;
+        f.state = q.state; f.attrs = attrs + b0 * N * 2; f.action = delta + b0 * plane;
+        f.p_instance = p_instance + b0 * n_p * p->n_instance; f.phys = phys ? phys + b0 * Pd : nullptr;
+        f.row_ptr = e.row_ptr; f.edge_recv = e.edge_recv; f.edge_send = e.edge_send;
+        f.pred_pos = q.pp; f.pred_motion = q.pm;
+        f.B = q.B; f.N = N; f.n_p = n_p; f.n_inst = p->n_instance; f.phys_dim = Pd;
+        f.pstep = m->cfg.pstep; f.clamp = m->cfg.motion_clamp;
+        AgStepArgs &st = run[k].st;
+        st.state = q.state; st.delta = delta + b0 * plane; st.pred_pos = q.pp;
+        st.obj_mask = obj_mask ? obj_mask + b0 * n_p : nullptr; st.repeat = repeat + b0;
+        st.out_seq = out_seq + b0 * n_p * 3; st.B = q.B; st.N = N; st.n_p = n_p; st.H = H;
+        st.height_mode = p->height_mode; st.raise = p->gripper_raise;
+    }
+    for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
+        for (int k = 0; k < parts; ++k) {
+            hipStream_t s = run[k].s;
+            { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
+            run_forward(m, part[k].f, s);
+            run[k].st.step = ai;
+            { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(run[k].st, s); }
+        }
+    for (int k = 0; k < parts && rc == AG_OK && state_final; ++k) {
+        const size_t b0 = (size_t)part[k].b0;
+        if (hipMemcpyAsync(state_final + b0 * H * plane, part[k].state, (size_t)part[k].B * H * plane * sizeof(float),
+                           hipMemcpyDeviceToDevice, run[k].s) != hipSuccess)
+            rc = AG_ERR_HIP;
+    }
+    m->max_blocks = saved_blocks;
+    for (int k = 1; k < parts; ++k) {
+        AG_HIP(hipEventRecord(m->ev_join[k], m->aux_stream[k]));
+        AG_HIP(hipStreamWaitEvent(s0, m->ev_join[k], 0));
+    }
+    if (rc != AG_OK) return fail(rc, "ag_rollout: hipMemcpyAsync failed");
     AG_HIP(hipGetLastError());
     return AG_OK;
 }

@@ -39,8 +39,6 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *edge_encode;   // RE0 RE1 RE2 | We(+b_rp)                     20 chunks
     const float4 *node_mid;      // PPb | Wr | Ws                               15 chunks
     const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
-    // same streams repacked fragment-major for the LDS-free kernels (ag_mlp.hip variant 1)
-    const float4 *node_encode_l2, *edge_encode_l2, *node_mid_l2, *node_last_l2;
 };
 
 struct AgFwdArgs {
@@ -60,8 +58,9 @@ struct AgFwdArgs {
     int B, N, n_p, n_inst, phys_dim, e_cap, pstep;
     float clamp;
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
-    int mlp_variant;   // 0: weights via double-buffered LDS chunks, 1: weights straight from L2 (no LDS/barriers)
-    int prio;          // experiment: alternate s_setprio between co-resident workgroups
+    float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
+    int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
+    int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
 };
 
 // kernel launchers (one translation unit each)

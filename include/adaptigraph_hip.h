@@ -54,6 +54,12 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
 int ag_model_update_weights(ag_model *m, const float *const *weights);
 int ag_model_destroy(ag_model *m);
 
+/* Engine knobs (all have sane defaults; used by bench.py for A/B passes):
+ *   "rollout_streams"  1..4  ag_rollout runs the batch as this many independent parts on separate streams (2)
+ *   "fuse_aggregate"   0/1   segment reduce inside node_update (1) or as its own kernel (0)
+ *   "max_blocks"       n     persistent grid size (default 2 x #CUs) */
+int ag_set_option(ag_model *m, const char *name, int value);
+
 /* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */
 int64_t ag_edge_capacity(int B, int N, int topk, int connect_tools_all, int max_tools);
 size_t ag_edges_workspace_bytes(int B, int N, int topk, int connect_tools_all, int max_tools);
