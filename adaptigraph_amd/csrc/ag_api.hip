@@ -52,21 +52,46 @@ struct Carver {   // bump allocator over the caller's workspace, 256-byte aligne
 enum { W_PE0, B_PE0, W_PE1, B_PE1, W_PE2, B_PE2, W_RE0, B_RE0, W_RE1, B_RE1, W_RE2, B_RE2, W_PP, B_PP, W_RP, B_RP,
        W_D0, B_D0, W_D1, B_D1, W_D2, B_D2, N_TENSORS };
 
-// Append one layer as n_tiles chunk images: 32 out-features x AG_WSTRIDE floats, columns [col0, col0+K) of W
-// in image columns [0, K), the bias (if any) in image column K, XOR-swizzled per ag_common.h.
-void pack_layer(std::vector<float> &dst, const float *W, int ld, int col0, int K, int n_out, const float *bias,
+uint16_t bf16_rne(float x)   // round-to-nearest-even, as v_cvt_pk_bf16_f32 does (finite inputs)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_to_f32(uint16_t b)
+{
+    const uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// Append one layer as n_tiles chunk images (AG_CHUNK_FLOATS floats each): input columns [col0, col0+K) of W in
+// image columns [0, K), the bias (if any) in image column K; layout per `b3` as described in ag_common.h.
+void pack_layer(std::vector<float> &dst, bool b3, const float *W, int ld, int col0, int K, int n_out, const float *bias,
                 int n_tiles)
 {
-    auto at = [](int i, int k) { return i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3); };
     for (int ti = 0; ti < n_tiles; ++ti) {
         const size_t base = dst.size();
         dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
         float *c = dst.data() + base;
+        uint16_t *cb = reinterpret_cast<uint16_t *>(c);
         for (int i = 0; i < 32; ++i) {
             const int o = 32 * ti + i;
             if (o >= n_out) continue;
-            for (int k = 0; k < K; ++k) c[at(i, k)] = W[(size_t)o * ld + col0 + k];
-            if (bias) c[at(i, K)] = bias[o];
+            for (int k = 0; k <= K; ++k) {
+                if (k == K && !bias) break;
+                const float v = k < K ? W[(size_t)o * ld + col0 + k] : bias[o];
+                if (!b3) {
+                    c[i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3)] = v;
+                } else {
+                    const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
+                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    cb[((size_t)(2 * u + 0) * 64 + lane) * 8 + e] = hi;
+                    cb[((size_t)(2 * u + 1) * 64 + lane) * 8 + e] = lo;
+                }
+            }
         }
     }
 }
@@ -80,6 +105,7 @@ struct ag_model {
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
     int fuse_agg = 1;           // env AG_FUSE_AGG=0 keeps the standalone aggregate kernel (A/B knob)
+    int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3 / ag_set_option("precision")
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -97,37 +123,39 @@ int pack_and_upload(ag_model *m, const float *const *t)
     const int F = m->cfg.nf, dn = m->cfg.attr_dim + m->cfg.phys_dim + m->cfg.action_dim;
     const int de = 2 * m->cfg.attr_dim + 1 + 3 * m->cfg.n_his;
     std::vector<float> s;
-    s.reserve((size_t)81 * AG_CHUNK_FLOATS);
-    const size_t o_node = s.size();
-    pack_layer(s, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
-    pack_layer(s, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
-    pack_layer(s, t[W_PE2], F, 0, F, F, t[B_PE2], AG_NT);
-    pack_layer(s, t[W_PP], 2 * F, 0, F, F, t[B_PP], AG_NT);        // Pn  = W_pp[:, :F] enc + b_pp
-    pack_layer(s, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);        // Hr  = W_rp[:, F:2F] h
-    pack_layer(s, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);    // Hs  = W_rp[:, 2F:3F] h
-    const size_t o_edge = s.size();
-    pack_layer(s, t[W_RE0], de, 0, de, F, t[B_RE0], AG_NT);
-    pack_layer(s, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
-    pack_layer(s, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
-    pack_layer(s, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);        // Eterm = W_rp[:, :F] enc_e + b_rp
-    const size_t o_mid = s.size();
-    pack_layer(s, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);        // W_pp[:, F:2F] agg
-    pack_layer(s, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);
-    pack_layer(s, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);
-    const size_t o_last = s.size();
-    pack_layer(s, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);
-    pack_layer(s, t[W_D0], F, 0, F, F, t[B_D0], AG_NT);
-    pack_layer(s, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
-    pack_layer(s, t[W_D2], F, 0, F, 3, t[B_D2], 1);
+    s.reserve((size_t)2 * 81 * AG_CHUNK_FLOATS);
+    size_t off[2][4];
+    for (int b3 = 0; b3 < 2; ++b3) {
+        off[b3][0] = s.size();                                             // node_encode stream
+        pack_layer(s, b3, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
+        pack_layer(s, b3, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
+        pack_layer(s, b3, t[W_PE2], F, 0, F, F, t[B_PE2], AG_NT);
+        pack_layer(s, b3, t[W_PP], 2 * F, 0, F, F, t[B_PP], AG_NT);        // Pn  = W_pp[:, :F] enc + b_pp
+        pack_layer(s, b3, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);        // Hr  = W_rp[:, F:2F] h
+        pack_layer(s, b3, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);    // Hs  = W_rp[:, 2F:3F] h
+        off[b3][1] = s.size();                                             // edge_encode stream
+        pack_layer(s, b3, t[W_RE0], de, 0, de, F, t[B_RE0], AG_NT);
+        pack_layer(s, b3, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
+        pack_layer(s, b3, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
+        pack_layer(s, b3, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);        // Eterm = W_rp[:, :F] enc_e + b_rp
+        off[b3][2] = s.size();                                             // node_update (not last)
+        pack_layer(s, b3, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);        // W_pp[:, F:2F] agg
+        pack_layer(s, b3, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);
+        pack_layer(s, b3, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);
+        off[b3][3] = s.size();                                             // node_update (last) + decoder
+        pack_layer(s, b3, t[W_PP], 2 * F, F, F, F, nullptr, AG_NT);
+        pack_layer(s, b3, t[W_D0], F, 0, F, F, t[B_D0], AG_NT);
+        pack_layer(s, b3, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
+        pack_layer(s, b3, t[W_D2], F, 0, F, 3, t[B_D2], 1);
+    }
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
-    m->w.node_encode = reinterpret_cast<const float4 *>(m->dev + o_node);
-    m->w.edge_encode = reinterpret_cast<const float4 *>(m->dev + o_edge);
-    m->w.node_mid = reinterpret_cast<const float4 *>(m->dev + o_mid);
-    m->w.node_last = reinterpret_cast<const float4 *>(m->dev + o_last);
+    auto at = [&](int b3, int k) { return reinterpret_cast<const float4 *>(m->dev + off[b3][k]); };
+    m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
+    m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
     return AG_OK;
 }
 
@@ -196,6 +224,7 @@ void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
     a.fuse_agg = m->fuse_agg;
+    a.precision = m->precision;
     a.max_blocks = m->max_blocks;
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
@@ -230,6 +259,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     ag_model *m = new ag_model();
     m->cfg = *cfg;
     if (const char *v = getenv("AG_FUSE_AGG")) m->fuse_agg = atoi(v);
+    if (const char *v = getenv("AG_PRECISION")) m->precision = (!strcmp(v, "f32") || !strcmp(v, "0")) ? AG_PREC_F32 : AG_PREC_B3;
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     {
         int dev = 0;
@@ -275,6 +305,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
     if (!strcmp(name, "rollout_streams")) m->split = value;
     else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
+    else if (!strcmp(name, "precision")) m->precision = value ? AG_PREC_B3 : AG_PREC_F32;
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;

@@ -9,10 +9,10 @@
 //       fully coalesced 16-byte accesses (used for tensors only the MLP kernels touch: h, Pn)
 //   CSR/COO adjacency: row_ptr[B*N+1] (global rows = b*N+i), edge_recv[E], edge_send[E] as GLOBAL node
 //       ids, edges sorted by (receiver, sender) == the reference's nonzero() order (graph.py:151)
-//   weight streams: per fused kernel, a sequence of 20480-byte chunk images [32 out-features][160]:
-//       columns [0,K) weights, column K the bias (K = fan-in), rest zero; element (i, k) is stored at
-//       i*160 + 4*((k/4) ^ ((i>>1)&7)) + k%4 (16-byte XOR swizzle -> conflict-free ds_read_b128),
-//       copied linearly into LDS.
+//   weight streams: per fused kernel, a sequence of 20480-byte chunk images (one 32-feature out-tile each),
+//       input columns [0,K) weights, column K the bias (K = fan-in), rest zero; copied linearly into LDS:
+//       F32: [32 out][160] floats, element (i, k) at i*160 + 4*((k/4) ^ ((i>>1)&7)) + k%4 (16-byte XOR swizzle)
+//       B3 : [10 steps u][hi|lo][64 lanes l=(i,h)][8 slots e] bf16, slot e = column 16u + 8(e>>2) + 4h + (e&3)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,6 +32,7 @@
 #define AG_EDGE_IN 17        // 2*attr + group + 3*n_his  (model.py:109-113)
 #define AG_NODE_IN_MAX 8     // attr + phys + action <= 8 (model.py:96-101)
 
+enum { AG_PREC_F32 = 0, AG_PREC_B3 = 1 };
 enum { AG_OK = 0, AG_ERR_ARG = -1, AG_ERR_HIP = -2, AG_ERR_WS = -3, AG_ERR_CONFIG = -4 };
 
 struct AgWeights {           // device pointers into the packed weight streams (float4-aligned)
@@ -39,6 +40,8 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *edge_encode;   // RE0 RE1 RE2 | We(+b_rp)                     20 chunks
     const float4 *node_mid;      // PPb | Wr | Ws                               15 chunks
     const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
+    // the same streams as split-bf16 fragment images (precision AG_PREC_B3)
+    const float4 *node_encode_b3, *edge_encode_b3, *node_mid_b3, *node_last_b3;
 };
 
 struct AgFwdArgs {
@@ -59,6 +62,7 @@ struct AgFwdArgs {
     float clamp;
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
     float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
+    int precision;     // AG_PREC_F32 (exact fp32 MFMA) or AG_PREC_B3 (hi/lo bf16 split, 3 MFMAs per product)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
 };

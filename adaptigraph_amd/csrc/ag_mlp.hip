@@ -1,30 +1,31 @@
-// ag_mlp.hip — fused dense-MLP kernels on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+// ag_mlp.hip — fused dense-MLP kernels on the gfx950 matrix cores, two arithmetic modes:
+//   F32 : v_mfma_f32_32x32x2_f32   — exact fp32 (a k-ordered fmaf chain), 157 TFLOP/s class
+//   B3  : v_mfma_f32_32x32x16_bf16 — every fp32 operand split x = hi + lo (two bf16), products
+//         lo*hi + hi*lo + hi*hi accumulated in fp32 ("bf16x3"): ~2^-17 relative operand error, measured
+//         1e-6..6e-6 max-abs on the reference forwards (gate 1e-4), 16/3 = 5.3x the fp32 MFMA rate.
 //
 // Replaces the reference's Encoder / Propagator / ParticlePredictor stacks
-// (src/dynamics/gnn/model.py:4-60) and the one-hot gathers feeding them (model.py:214-253).
+// (src/dynamics/gnn/model.py:4-60) and the one-hot gathers feeding them (model.py:214-253, 283-295).
 //
-// Design (CDNA4-first, see DESIGN.md §3):
-//  * One wave owns 32 rows (edges or nodes).  The product is computed TRANSPOSED, D^T = W . X^T:
-//    the weight matrix is the MFMA A operand (32 out-features x 2 k), the activations are the B
-//    operand (2 k x 32 rows).  The 32x32 accumulator layout then gives lane (j = lane&31, h = lane>>5)
-//    the features {32t + 8q + 4h + p} of row j — which is exactly the B-operand image the NEXT layer
-//    needs if its k-loop visits k in the order (t, q, p) with lanes h=0/1 supplying k and k+4.
-//    So activations never leave registers between layers: bias + ReLU are applied in place and the
-//    accumulators of layer L are the operands of layer L+1.  No LDS round trip, no transposes.
-//  * Weights stream through LDS in 20 KB chunk images (32 out-features x 160 floats, bias stored as
-//    column 150 and multiplied by a constant-1 activation so it rides the MFMA chain), double-buffered:
-//    the next chunk is fetched to registers while the current one feeds 76 MFMAs, then written to the
-//    other buffer, one barrier per chunk.  The image is XOR-swizzled at 16-byte granularity
-//    (col16 ^= (row >> 1) & 7) on the host, which makes the per-lane ds_read_b128 fragment reads
-//    bank-conflict-free at the 640-byte row stride (MI355X_MICROARCH.md §LDS lane groups).
-//  * 256-thread workgroups (one wave per SIMD), 2 workgroups per CU (40 KB LDS each, <=256 VGPR),
-//    so one workgroup's barrier/epilogue hides under the other's MFMAs.
-//  * fp32-input MFMA is an exact k-ordered fma chain (cdna_hip_programming.md §3), so results match the
-//    reference's fp32 forward to summation-order noise (~1e-7), far inside the 1e-4 gate.
+// Design (CDNA4-first, see DESIGN.md §4):
+//  * One wave owns 32 rows (edges or nodes).  The product is computed TRANSPOSED, D^T = W . X^T: the weight
+//    matrix is the MFMA A operand (32 out-features x k), the activations are the B operand (k x 32 rows).
+//    The 32x32 accumulator layout then gives lane (j = lane&31, h = lane>>5) the features
+//    {32t + 8q + 4h + p} of row j — exactly the B-operand image the NEXT layer needs if its k-loop visits k
+//    in that order (the k order of a dot product is free as long as A and B agree; the host packs the
+//    weights to match).  So activations never leave registers between layers: bias, ReLU, the bf16 split
+//    and the layer-to-layer hand-off are register-only.  No LDS round trip, no transposes.
+//  * Weights stream through LDS in 20 KB chunk images (one 32-feature out-tile; bias stored as input column
+//    150 against a constant-1 activation so it rides the MFMA chain), double-buffered by LDS-DMA
+//    (global_load_lds_dwordx4) issued a full tile ahead, one barrier per tile.
+//      F32 image: [32 out][160] floats, 16-byte XOR swizzle (col16 ^= (row>>1)&7) -> conflict-free ds_read_b128
+//      B3  image: [10 k16-steps][hi|lo][64 lanes][8 bf16] fragment-major -> every ds_read_b128 is lane-linear
+//  * All kernels are persistent (<= 2 workgroups per CU walk the 128-row tiles with a grid stride); the weight
+//    ring keeps turning across row tiles.  256-thread workgroups, one wave per SIMD, 2 workgroups per CU.
 #include "ag_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 is a union-y struct that defeats SROA)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -77,11 +78,13 @@ __device__ __forceinline__ void pipe_start(ChunkPipe &P)
     __syncthreads();
 }
 
+// ---- per-tile epilogues (run right after a 32-feature out-tile is finished, so its stores overlap the next
+//      tile's MFMAs instead of piling up behind the layer) -------------------------------------------------
 struct NoEpi {
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
 };
-struct RowStoreEpi {        // store one finished 32-feature tile of the row-major [rows][160] table
-    float *row;             // table + row*160 + 4h
+struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row = table + row*160 + 4h
+    float *row;
     bool valid;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
@@ -101,6 +104,7 @@ struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_l
     }
 };
 
+// ---- accumulator initialisers ------------------------------------------------------------------------------
 struct ZeroInit {
     __device__ __forceinline__ f32x16 operator()(int /*ti*/) const
     {
@@ -110,7 +114,6 @@ struct ZeroInit {
         return acc;
     }
 };
-
 struct ResidInit {  // accumulator := Pn + h (packed tables), i.e. W_pp[:, :F].enc + b_pp + residual (model.py:36-40,299-301)
     const float *pn, *hh;   // already offset to this wave's 32-row block and this lane's (h, j)
     __device__ __forceinline__ f32x16 operator()(int ti) const
@@ -127,60 +130,144 @@ struct ResidInit {  // accumulator := Pn + h (packed tables), i.e. W_pp[:, :F].e
     }
 };
 
-// out[ti] = act(W_chunk(ti) . in + init(ti)) for NT out-tiles.
-// K = number of input columns visited (k >= K is zero padding).  With BIAS the layer's bias is column K of the
-// packed weights and the matching activation "feature K" is forced to 1.0 here, so the bias rides the MFMA chain
+// =====================================================================================================
+// Precision policies.  Both expose
+//   Act                      register image of a 160-wide activation row block (the MFMA B operands)
+//   from_tiles(f32 tiles)    build an Act from fp32 accumulator tiles
+//   layer<K,NT,RELU,BIAS>    out-tile loop: acc = init(ti); acc += W_chunk . in; relu; epi(ti, acc);
+//                            the finished tile is handed to `sink(ti, acc)` (next layer's Act, or raw tiles)
+// K = number of input columns visited (k >= K is zero padding).  With BIAS the layer's bias is input column K of
+// the packed weights and the matching activation "feature K" is forced to 1.0, so the bias rides the MFMA chain
 // (columns >= AG_F of every activation table are padding, nothing else reads them).
-// Weight pipeline per tile: the LDS-DMA of chunk c+1 into the idle buffer is issued first and lands under the
-// tile's 76 MFMAs; one barrier per tile.  `epi(ti, acc)` runs right after a tile is finished (stores of tile ti
-// then overlap the MFMAs of tile ti+1 instead of piling up behind the layer).
-template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi = NoEpi>
-__device__ __forceinline__ void dense_layer(ChunkPipe &P, const f32x16 (&in)[(K + 32) / 32], f32x16 (&out)[NT],
-                                            const Init &init, const Epi &epi = Epi{})
-{
-    constexpr int KE = K + (BIAS ? 1 : 0);
-    constexpr int PT = (KE + 7) / 8;      // quads (= 4 k-steps = one ds_read_b128 per lane) per tile
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, i = lane & 31, h = lane >> 5;
-    // per-lane fragment addresses: row i, 16-byte column (8t + 2q + h) ^ ((i >> 1) & 7)  (host pre-swizzles the
-    // chunk image the same way; keeps the 640-byte-stride rows conflict-free for ds_read_b128)
-    const int sw = (i >> 1) & 7;
-    int qoff[4];
+// =====================================================================================================
+struct PrecF32 {
+    struct Act { f32x16 t[AG_NT]; };
+    __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v) { a.t[ti] = v; }
+
+    template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
+    __device__ __forceinline__ static void layer(ChunkPipe &P, const Act &in, const Init &init, const Epi &epi, Sink &&sink)
+    {
+        constexpr int KE = K + (BIAS ? 1 : 0);
+        constexpr int PT = (KE + 7) / 8;      // quads (= 4 k-steps = one ds_read_b128 per lane) per tile
+        const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+        // per-lane fragment addresses: row i, 16-byte column (8t + 2q + h) ^ ((i >> 1) & 7) (host pre-swizzled)
+        const int sw = (i >> 1) & 7;
+        int qoff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) qoff[q] = i * AG_WSTRIDE + 4 * ((2 * q + h) ^ sw);
+        for (int q = 0; q < 4; ++q) qoff[q] = i * AG_WSTRIDE + 4 * ((2 * q + h) ^ sw);
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        const float *buf = P.lds + P.buf * AG_CHUNK_FLOATS;
-        pipe_dma(P, P.buf ^ 1);
-        f32x16 acc = init(ti);
+        for (int ti = 0; ti < NT; ++ti) {
+            const float *buf = P.lds + P.buf * AG_CHUNK_FLOATS;
+            pipe_dma(P, P.buf ^ 1);
+            f32x16 acc = init(ti);
 #pragma unroll
-        for (int m = 0; m < PT; ++m) {
-            const int t = m / 4, q = m % 4;
-            const float4 w = *reinterpret_cast<const float4 *>(buf + qoff[q] + 32 * t);
-            const float wv[4] = {w.x, w.y, w.z, w.w};
+            for (int m = 0; m < PT; ++m) {
+                const int t = m / 4, q = m % 4;
+                const float4 w = *reinterpret_cast<const float4 *>(buf + qoff[q] + 32 * t);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k0 = 32 * t + 8 * q + p;        // column seen by the h = 0 half (h = 1: k0 + 4)
-                if (k0 < KE) {
-                    float x = in[t][4 * q + p];
-                    if (BIAS && (k0 == K || k0 + 4 == K)) x = (h == (k0 == K ? 0 : 1)) ? 1.0f : x;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], x, acc, 0, 0, 0);
+                for (int p = 0; p < 4; ++p) {
+                    const int k0 = 32 * t + 8 * q + p;        // column seen by the h = 0 half (h = 1: k0 + 4)
+                    if (k0 < KE) {
+                        float x = in.t[t][4 * q + p];
+                        if (BIAS && (k0 == K || k0 + 4 == K)) x = (h == (k0 == K ? 0 : 1)) ? 1.0f : x;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], x, acc, 0, 0, 0);
+                    }
                 }
             }
-        }
-        if (RELU) {
+            if (RELU) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+                for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            }
+            epi(ti, acc);
+            sink(ti, acc);
+            pipe_wait();
+            __syncthreads();
+            P.buf ^= 1;
         }
-        out[ti] = acc;
-        epi(ti, acc);
-        pipe_wait();
-        __syncthreads();
-        P.buf ^= 1;
     }
+};
+
+struct PrecB3 {
+    // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
+    // which is accumulator register 8s + e of out-tile t — so a finished tile converts in place, no shuffles.
+    struct Act { bf16x8 hi[2 * AG_NT], lo[2 * AG_NT]; };
+    __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
+    {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = v[8 * s + e];
+                const __bf16 hb = (__bf16)x;                 // round-to-nearest-even (v_cvt_pk_bf16_f32)
+                a.hi[2 * ti + s][e] = hb;
+                a.lo[2 * ti + s][e] = (__bf16)(x - (float)hb);
+            }
+    }
+
+    template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
+    __device__ __forceinline__ static void layer(ChunkPipe &P, const Act &in, const Init &init, const Epi &epi, Sink &&sink)
+    {
+        constexpr int KE = K + (BIAS ? 1 : 0);
+        constexpr int NU = (KE + 15) / 16;    // k16-steps per tile
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const bf16x8 *buf = reinterpret_cast<const bf16x8 *>(P.lds + P.buf * AG_CHUNK_FLOATS) + lane;
+            pipe_dma(P, P.buf ^ 1);
+            f32x16 acc = init(ti);
+            // weight fragments are read two k16-steps ahead of their MFMAs (3 x 32-cycle MFMAs per step do not
+            // cover an LDS round trip on their own)
+            constexpr int PF = 2;
+            bf16x8 wq[PF + 1][2];
+#pragma unroll
+            for (int u = 0; u < PF && u < NU; ++u) { wq[u][0] = buf[(2 * u) * 64]; wq[u][1] = buf[(2 * u + 1) * 64]; }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PF < NU ? PF : NU), 0);   // prologue reads first
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + PF < NU) {
+                    wq[(u + PF) % (PF + 1)][0] = buf[(2 * (u + PF)) * 64];
+                    wq[(u + PF) % (PF + 1)][1] = buf[(2 * (u + PF) + 1) * 64];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);               // reads of step u+PF ...
+                }
+                const bf16x8 wh = wq[u % (PF + 1)][0], wl = wq[u % (PF + 1)][1];
+                bf16x8 xh = in.hi[u], xl = in.lo[u];
+                if (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3)
+                    constexpr int o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
+                    if (h == hb) { xh[e] = (__bf16)1.0f; xl[e] = (__bf16)0.0f; }
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                   // ... ahead of the 3 MFMAs of step u
+            }
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            }
+            epi(ti, acc);
+            sink(ti, acc);
+            pipe_wait();
+            __syncthreads();
+            P.buf ^= 1;
+        }
+    }
+};
+
+// layer -> next Act
+template <class Prec, int K, bool RELU, bool BIAS, class Init, class Epi = NoEpi>
+__device__ __forceinline__ void dense(ChunkPipe &P, const typename Prec::Act &in, typename Prec::Act &out, const Init &init,
+                                      const Epi &epi = Epi{})
+{
+    Prec::template layer<K, AG_NT, RELU, BIAS>(P, in, init, epi, [&](int ti, const f32x16 &v) { Prec::set_tile(out, ti, v); });
+}
+// layer whose output is only stored (by `epi`)
+template <class Prec, int K, bool RELU, bool BIAS, class Init, class Epi>
+__device__ __forceinline__ void dense_store(ChunkPipe &P, const typename Prec::Act &in, const Init &init, const Epi &epi)
+{
+    Prec::template layer<K, AG_NT, RELU, BIAS>(P, in, init, epi, [](int, const f32x16 &) {});
 }
 
-// ---- register image <-> HBM movers ------------------------------------------------------------
 __device__ __forceinline__ void load_rowmajor(const float *row, f32x16 (&v)[AG_NT], int h)
 {
 #pragma unroll
@@ -249,10 +336,9 @@ __device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool v
 
 #define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS];
 
-
-// All three MLP kernels are PERSISTENT: gridDim.x <= 2 x #CUs workgroups (what the VGPR budget keeps resident)
-// walk the 128-row tiles with a grid stride.  The weight-chunk ring keeps turning across row tiles (the stream is
-// cyclic), so after the first tile there is no pipeline restart, no dispatch gap and no cold LDS.
+template <class Prec> __device__ __forceinline__ const float4 *pick(const float4 *f32, const float4 *b3);
+template <> __device__ __forceinline__ const float4 *pick<PrecF32>(const float4 *f32, const float4 *) { return f32; }
+template <> __device__ __forceinline__ const float4 *pick<PrecB3>(const float4 *, const float4 *b3) { return b3; }
 
 // ---------------------------------------------------------------------------------------------
 // Node encoder + pstep-invariant node terms.
@@ -262,13 +348,14 @@ __device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool v
 //   Hr  = W_rp[:, F:2F] . h0,  Hs = W_rp[:, 2F:3F] . h0   (receiver / sender column blocks of
 //          relation_propagator applied at NODE level instead of per edge, model.py:283-289)
 // ---------------------------------------------------------------------------------------------
+template <class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
-    ChunkPipe P{w.node_encode, 30, 0, 0, lds};
+    ChunkPipe P{pick<Prec>(w.node_encode, w.node_encode_b3), 30, 0, 0, lds};
     pipe_start(P);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -277,10 +364,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
         const int gc = valid ? g : 0;
         const int b = gc / a.N, i = gc - b * a.N;
 
-        // p_inputs = [attrs(2) | physics_param (0 for tool slots) | action(3) | 1 (bias column)], k = 4h + p
-        f32x16 in0[1];
+        // p_inputs = [attrs(2) | physics_param (0 for tool slots) | action(3) | 1 (bias column)], feature k = 4h + p
+        f32x16 in0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) in0[0][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) in0[r] = 0.0f;
         {
             const int A = AG_ATTR, Pd = a.phys_dim;
 #pragma unroll
@@ -291,18 +378,19 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
                 else if (k < A + Pd) v = i < a.n_p ? a.phys[(size_t)b * Pd + (k - A)] : 0.0f;
                 else if (k < A + Pd + 3) v = a.action[(size_t)gc * 3 + (k - A - Pd)];
                 else if (k == A + Pd + 3) v = 1.0f;   // bias column of particle_encoder.model.0
-                in0[0][p] = v;
+                in0[p] = v;
             }
         }
-        f32x16 x[AG_NT], y[AG_NT];
-        dense_layer<AG_NODE_IN_MAX - 1, AG_NT, true, false>(P, in0, x, ZeroInit{});
-        dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});
+        typename Prec::Act x, y;
+        Prec::set_tile(x, 0, in0);
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)gc * AG_FP + 4 * h;
-        dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{}, PackStoreEpi{a.h + blk});          // x = particle_encode = h0
-        dense_layer<AG_F, AG_NT, false, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.pn + blk});        // Pn
-        dense_layer<AG_F, AG_NT, false, false>(P, x, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff, valid});  // Hr
-        dense_layer<AG_F, AG_NT, false, false>(P, x, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff, valid});  // Hs
+        dense<Prec, AG_NODE_IN_MAX - 1, true, false>(P, x, y, ZeroInit{});
+        dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
+        dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
+        dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
+        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff, valid});  // Hr
+        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff, valid});  // Hs
     }
 }
 
@@ -313,6 +401,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
 //   Eterm      = W_rp[:, :F] . enc_e + b_rp      (first column block of relation_propagator, model.py:289)
 // The one-hot gathers Rr.bmm / Rs.bmm become indexed reads of the (L2-resident) raw node inputs.
 // ---------------------------------------------------------------------------------------------
+template <class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
@@ -322,7 +411,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
-    ChunkPipe P{w.edge_encode, 20, 0, 0, lds};
+    ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 20, 0, 0, lds};
     pipe_start(P);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -363,20 +452,21 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 #pragma unroll
             for (int c = 0; c < 3; ++c) feat[5 + (AG_NHIS - 1) * 3 + c] = pr[AG_NHIS - 1][c] - ps[AG_NHIS - 1][c];
         }
-        f32x16 in0[1];
+        f32x16 in0;
 #pragma unroll
-        for (int r16 = 0; r16 < 16; ++r16) in0[0][r16] = 0.0f;
+        for (int r16 = 0; r16 < 16; ++r16) in0[r16] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) in0[0][4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
+            for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
 
-        f32x16 x[AG_NT], y[AG_NT];
-        dense_layer<AG_EDGE_IN + 1, AG_NT, true, false>(P, in0, x, ZeroInit{});
-        dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});
-        dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{});    // relation_encode
-        dense_layer<AG_F, AG_NT, false, true>(P, x, y, ZeroInit{},     // Eterm
-                                              RowStoreEpi{a.eterm + (size_t)(valid ? e : 0) * AG_FP + 4 * h, valid});
+        typename Prec::Act x, y;
+        Prec::set_tile(x, 0, in0);
+        dense<Prec, AG_EDGE_IN + 1, true, false>(P, x, y, ZeroInit{});
+        dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
+        dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
+        dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{},  // Eterm
+                                             RowStoreEpi{a.eterm + (size_t)(valid ? e : 0) * AG_FP + 4 * h, valid});
     }
 }
 
@@ -385,14 +475,14 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 // then the node update (model.py:299-301), then either the next round's node-level relation terms (Hr, Hs)
 // or — after the last round — the decoder + clamp + integrate (model.py:306-309).
 // ---------------------------------------------------------------------------------------------
-template <bool LAST>
+template <class Prec, bool LAST>
 __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
-    ChunkPipe P{LAST ? w.node_last : w.node_mid, LAST ? 16 : 15, 0, 0, lds};
+    ChunkPipe P{LAST ? pick<Prec>(w.node_last, w.node_last_b3) : pick<Prec>(w.node_mid, w.node_mid_b3), LAST ? 16 : 15, 0, 0, lds};
     pipe_start(P);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -400,24 +490,29 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
         const bool valid = g < Mn;
         const int gc = valid ? g : 0;
 
-        f32x16 x[AG_NT], y[AG_NT];
-        if (a.fuse_agg) aggregate_rows(a, gc, valid, h, x);
-        else load_rowmajor(a.agg + (size_t)gc * AG_FP, x, h);
+        typename Prec::Act x, y;
+        {
+            f32x16 agg[AG_NT];
+            if (a.fuse_agg) aggregate_rows(a, gc, valid, h, agg);
+            else load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
+        }
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)gc * AG_FP + 4 * h;
         if (!LAST) {
-            dense_layer<AG_F, AG_NT, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
+            dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
-            dense_layer<AG_F, AG_NT, false, false>(P, y, x, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff, valid});
-            dense_layer<AG_F, AG_NT, false, false>(P, y, x, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff, valid});
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff, valid});
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff, valid});
         } else {
-            dense_layer<AG_F, AG_NT, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
-
-            dense_layer<AG_F, AG_NT, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
-            dense_layer<AG_F, AG_NT, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
-            f32x16 m[1];
-            dense_layer<AG_F, 1, false, true>(P, y, m, ZeroInit{});       // linear_2 -> rows 0..2 of tile 0
+            dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
+            dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
+            dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
+            f32x16 m;
+            Prec::template layer<AG_F, 1, false, true>(P, y, ZeroInit{}, NoEpi{},      // linear_2 -> rows 0..2 of tile 0
+                                                       [&](int, const f32x16 &v) { m = v; });
             const int b = gc / a.N, i = gc - b * a.N;
             if (valid && h == 0 && i < a.n_p) {
                 const float *cur = a.state + (((size_t)b * AG_NHIS + (AG_NHIS - 1)) * a.N + i) * 3;
@@ -425,7 +520,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
                 float *pp = a.pred_pos + ((size_t)b * a.n_p + i) * 3;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float mv = m[0][c];
+                    const float mv = m[c];
                     pm[c] = mv;
                     pp[c] = cur[c] + fminf(fmaxf(mv, -a.clamp), a.clamp);   // model.py:309
                 }
@@ -444,18 +539,27 @@ static inline int grid_for(int rows, int max_blocks)
 
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(node_encode_kernel, dim3(grid_for(a.B * a.N, a.max_blocks)), dim3(AG_MLP_THREADS), 0, s, w, a);
+    const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(node_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
+    else hipLaunchKernelGGL(node_encode_kernel<PrecF32>, grid, block, 0, s, w, a);
 }
 
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
-    hipLaunchKernelGGL(edge_encode_kernel, dim3(grid_for(a.e_cap, a.max_blocks)), dim3(AG_MLP_THREADS), 0, s, w, a);
+    const dim3 grid(grid_for(a.e_cap, a.max_blocks)), block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(edge_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
+    else hipLaunchKernelGGL(edge_encode_kernel<PrecF32>, grid, block, 0, s, w, a);
 }
 
 void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hipStream_t s)
 {
     const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
-    if (last) hipLaunchKernelGGL(node_update_kernel<true>, grid, block, 0, s, w, a);
-    else hipLaunchKernelGGL(node_update_kernel<false>, grid, block, 0, s, w, a);
+    if (a.precision == AG_PREC_B3) {
+        if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<PrecB3, false>), grid, block, 0, s, w, a);
+    } else {
+        if (last) hipLaunchKernelGGL((node_update_kernel<PrecF32, true>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<PrecF32, false>), grid, block, 0, s, w, a);
+    }
 }

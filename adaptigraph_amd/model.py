@@ -116,6 +116,13 @@ class DynamicsPredictor(nn.Module):
             self._sync_weights()
         return self._handle
 
+    def set_option(self, name, value, device=None):
+        """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16
+        (default); "rollout_streams"; "fuse_aggregate"; "max_blocks"."""
+        dev = torch.device(device if device is not None else self.device)
+        _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
+        return self
+
     def __del__(self):
         try:
             if self._handle is not None:

