@@ -104,9 +104,11 @@ struct ag_model {
     size_t dev_floats = 0;
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
-    int fuse_agg = 1;           // env AG_FUSE_AGG=0 keeps the standalone aggregate kernel (A/B knob)
-    int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3 / ag_set_option("precision")
+    int fuse_agg = 0;           // 1: segment reduce inside node_update (env AG_FUSE_AGG / "fuse_aggregate"); measured slower
+    int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3|fast / ag_set_option("precision", 0|1|2)
+    int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
+    int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -220,20 +222,31 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
     ~Timed() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
+void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
     a.fuse_agg = m->fuse_agg;
     a.precision = m->precision;
+    a.eterm_half = m->eterm_half;
     a.max_blocks = m->max_blocks;
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
+}
+
+void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
     for (int p = 0; p < a.pstep; ++p) {
         if (!a.fuse_agg) { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(a, s); }
         { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, a, p == a.pstep - 1, s); }
         std::swap(a.hr, a.hr_out);
         std::swap(a.hs, a.hs_out);
     }
+}
+
+void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
+    run_encode(m, a, s);
+    run_propagate(m, a, s);
 }
 
 }  // namespace
@@ -259,8 +272,13 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     ag_model *m = new ag_model();
     m->cfg = *cfg;
     if (const char *v = getenv("AG_FUSE_AGG")) m->fuse_agg = atoi(v);
-    if (const char *v = getenv("AG_PRECISION")) m->precision = (!strcmp(v, "f32") || !strcmp(v, "0")) ? AG_PREC_F32 : AG_PREC_B3;
+    if (const char *v = getenv("AG_PRECISION")) {
+        const int mode = (!strcmp(v, "f32") || !strcmp(v, "0")) ? 0 : (!strcmp(v, "bf16x3") || !strcmp(v, "1")) ? 1 : 2;
+        m->precision = mode ? AG_PREC_B3 : AG_PREC_F32;
+        m->eterm_half = mode == 2;
+    }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
+    if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -305,7 +323,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
     if (!strcmp(name, "rollout_streams")) m->split = value;
     else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
-    else if (!strcmp(name, "precision")) m->precision = value ? AG_PREC_B3 : AG_PREC_F32;
+    else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
@@ -534,7 +552,14 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         for (int k = 0; k < parts; ++k) {
             hipStream_t s = run[k].s;
             { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
-            run_forward(m, part[k].f, s);
+            run_encode(m, part[k].f, s);
+            if (ai == 1 && k == 0 && parts > 1 && m->stagger) {
+                // phase offset: the other parts start once part 0 has finished its first MFMA-bound encode stage, so
+                // from then on one stream's HBM-bound segment reduce co-runs with another stream's MFMA-bound stage
+                AG_HIP(hipEventRecord(m->ev_fork, s0));
+                for (int kk = 1; kk < parts; ++kk) AG_HIP(hipStreamWaitEvent(m->aux_stream[kk], m->ev_fork, 0));
+            }
+            run_propagate(m, part[k].f, s);
             run[k].st.step = ai;
             { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(run[k].st, s); }
         }

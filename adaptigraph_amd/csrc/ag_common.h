@@ -63,6 +63,7 @@ struct AgFwdArgs {
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
     float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
     int precision;     // AG_PREC_F32 (exact fp32 MFMA) or AG_PREC_B3 (hi/lo bf16 split, 3 MFMAs per product)
+    int eterm_half;    // 1: the Eterm table is fp16 in accumulator order (precision mode 2)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
 };

@@ -94,6 +94,20 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
             *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 };
+struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
+    _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
+    bool valid;
+    __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
+    {
+        if (!valid) return;
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 a, b;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = (_Float16)v[r]; b[r] = (_Float16)v[8 + r]; }
+        *reinterpret_cast<h8 *>(row + 32 * ti) = a;
+        *reinterpret_cast<h8 *>(row + 32 * ti + 8) = b;
+    }
+};
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
     float *blk_lane;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
@@ -287,6 +301,7 @@ __device__ __forceinline__ void load_rowmajor(const float *row, f32x16 (&v)[AG_N
 // instruction 32 rows x 32 contiguous bytes; each 128-B line of an Eterm row is consumed by 4 consecutive
 // instructions of the same wave (L1 hits), so HBM sees every Eterm byte once.  The loop runs to the largest
 // in-degree in the wave with the shorter rows predicated off.
+template <bool HALF>
 __device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool valid, int h, f32x16 (&x)[AG_NT])
 {
     int e0 = 0, deg = 0;
@@ -303,28 +318,39 @@ __device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool v
     for (int t = 0; t < AG_NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[t][r] = 0.0f;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     for (int d = 0; d < maxdeg; ++d) {
         const bool act = d < deg;
         const int e = act ? e0 + d : 0;
         const int sidx = a.edge_send[e];
         const float *er = a.eterm + (size_t)e * AG_FP + 4 * h;
+        const _Float16 *er16 = reinterpret_cast<const _Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h;
         const float *sr = a.hs + (size_t)sidx * AG_FP + 4 * h;
 #pragma unroll
         for (int t = 0; t < AG_NT; ++t) {
-            float4 ev[4], sv[4];
+            float ev[16];
+            float4 sv[4];
+            if (HALF) {
+                const h8 lo = *reinterpret_cast<const h8 *>(er16 + 32 * t), hi = *reinterpret_cast<const h8 *>(er16 + 32 * t + 8);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { ev[r] = (float)lo[r]; ev[8 + r] = (float)hi[r]; }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (32 * t + 8 * q < 152) {
-                    ev[q] = *reinterpret_cast<const float4 *>(er + 32 * t + 8 * q);
+                    if (!HALF) {
+                        const float4 v = *reinterpret_cast<const float4 *>(er + 32 * t + 8 * q);
+                        ev[4 * q] = v.x; ev[4 * q + 1] = v.y; ev[4 * q + 2] = v.z; ev[4 * q + 3] = v.w;
+                    }
                     sv[q] = *reinterpret_cast<const float4 *>(sr + 32 * t + 8 * q);
                 }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (32 * t + 8 * q < 152) {
-                    const float m0 = fmaxf((ev[q].x + hr[t][4 * q + 0]) + sv[q].x, 0.0f);
-                    const float m1 = fmaxf((ev[q].y + hr[t][4 * q + 1]) + sv[q].y, 0.0f);
-                    const float m2 = fmaxf((ev[q].z + hr[t][4 * q + 2]) + sv[q].z, 0.0f);
-                    const float m3 = fmaxf((ev[q].w + hr[t][4 * q + 3]) + sv[q].w, 0.0f);
+                    const float m0 = fmaxf((ev[4 * q + 0] + hr[t][4 * q + 0]) + sv[q].x, 0.0f);
+                    const float m1 = fmaxf((ev[4 * q + 1] + hr[t][4 * q + 1]) + sv[q].y, 0.0f);
+                    const float m2 = fmaxf((ev[4 * q + 2] + hr[t][4 * q + 2]) + sv[q].z, 0.0f);
+                    const float m3 = fmaxf((ev[4 * q + 3] + hr[t][4 * q + 3]) + sv[q].w, 0.0f);
                     x[t][4 * q + 0] += act ? m0 : 0.0f;
                     x[t][4 * q + 1] += act ? m1 : 0.0f;
                     x[t][4 * q + 2] += act ? m2 : 0.0f;
@@ -465,8 +491,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
         dense<Prec, AG_EDGE_IN + 1, true, false>(P, x, y, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
-        dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{},  // Eterm
-                                             RowStoreEpi{a.eterm + (size_t)(valid ? e : 0) * AG_FP + 4 * h, valid});
+        if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) +
+                                                                                   (size_t)(valid ? e : 0) * AG_FP + 16 * h, valid});
+        else
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)(valid ? e : 0) * AG_FP + 4 * h, valid});
     }
 }
 
@@ -493,7 +522,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
         typename Prec::Act x, y;
         {
             f32x16 agg[AG_NT];
-            if (a.fuse_agg) aggregate_rows(a, gc, valid, h, agg);
+            if (a.fuse_agg) { if (a.eterm_half) aggregate_rows<true>(a, gc, valid, h, agg); else aggregate_rows<false>(a, gc, valid, h, agg); }
             else load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
 #pragma unroll
             for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);

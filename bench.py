@@ -34,7 +34,13 @@ from adaptigraph_amd.forward_dynamics import dynamics                  # noqa: E
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+PEAK_HBM_GBS = 8000.0                # HBM3E spec; 6290 GB/s is the measured float4-copy ceiling (same file)
 FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # edge encoder 17->150->150->150 + W_rp[:, :150] block
+PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
+DTYPE = {"f32": "f32 (exact fp32 MFMA)",
+         "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
+         "fast": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate; per-edge table stored f16"}
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
 
@@ -72,6 +78,8 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event roofline pass")
+    ap.add_argument("--precision", default="fast", choices=sorted(PRECISIONS),
+                    help="engine arithmetic mode; all three pass the 1e-4 parity gate (tests/test_gpu_parity.py)")
     ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
     args = ap.parse_args()
 
@@ -117,6 +125,7 @@ def main():
     def set_opt(name, value):
         _lib.check(L.ag_set_option(h, name.encode(), int(value)), f"ag_set_option({name})")
 
+    set_opt("precision", PRECISIONS[args.precision])
     set_opt("rollout_streams", args.streams)
     for _ in range(args.warmup):
         out = one_pass()
@@ -149,15 +158,31 @@ def main():
         kernels = {name: {"ms_per_launch": ms[i] / max(int(cnt[i]), 1), "launches": int(cnt[i])}
                    for i, name in enumerate(_lib.KERNEL_CLASSES)}
         k = _lib.KERNEL_CLASSES.index("edge_encode")
+        roof_hbm = None
         if cnt[k] > 0 and ms[k] > 0:
             avg_s = ms[k] / cnt[k] * 1e-3
-            flop_per_launch = FLOP_PER_EDGE * edges.value / cnt[k]
-            achieved = flop_per_launch / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                    "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": edges.value / cnt[k],
-                    "flop_per_edge": FLOP_PER_EDGE,
+            e_per = edges.value / cnt[k]
+            b3 = args.precision != "f32"
+            # algorithmic FLOP of the kernel's arithmetic: the split-bf16 modes need 3 bf16 products per fp32 product
+            flop_edge = FLOP_PER_EDGE * (3 if b3 else 1)
+            peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
+            achieved = flop_edge * e_per / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": flop_edge,
+                    "fp32_equivalent_tflops": FLOP_PER_EDGE * e_per / avg_s / 1e12,
+                    "mfma": "v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi)" if b3 else "v_mfma_f32_32x32x2_f32",
                     "measured": f"HIP events on the launch stream, {n_prof} single-stream passes after the timed region"}
+            ka = _lib.KERNEL_CLASSES.index("aggregate")
+            if cnt[ka] > 0 and ms[ka] > 0:
+                # segment reduce: Eterm streamed once (640 B/edge fp32, 320 B f16), Hs rows gathered (first touch from
+                # HBM once per node, then L2), Hr read + agg written per node (SURVEY §8d B_alg terms)
+                n_nodes = args.batch * (wl["n_obj"] + synth.MATERIALS[args.material]["n_tools"])
+                nbytes = e_per * (320 if args.precision == "fast" else 640) + n_nodes * 3 * 640
+                a_s = ms[ka] / cnt[ka] * 1e-3
+                roof_hbm = {"bound": "hbm", "kernel": "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
+                            "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -169,13 +194,13 @@ def main():
             "metric": "rollout graph-steps/s (batch x rollout steps / wall; edge build + GNN forward + state update per graph-step)",
             "value": B_global * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {args.batch}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
                                    f"{args.material} {wl['n_obj']} particles, batch {args.batch}/GPU, {T}-step rollout",
                        "global_batch": B_global, "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather", "rollout_streams": args.streams,
-                       "weights": "seed-0 random init (reference default init)", "precision": "fp32 MFMA (exact f32)"},
-            "roofline": roof, "kernels": kernels,
+                       "weights": "seed-0 random init (reference default init)", "precision": args.precision},
+            "roofline": roof, "roofline_hbm": roof_hbm if not args.no_profile else None, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"], T)

@@ -56,10 +56,11 @@ int ag_model_destroy(ag_model *m);
 
 /* Engine knobs (all have sane defaults; used by bench.py for A/B passes):
  *   "rollout_streams"  1..4  ag_rollout runs the batch as this many independent parts on separate streams (2)
- *   "fuse_aggregate"   0/1   segment reduce inside node_update (1) or as its own kernel (0)
+ *   "fuse_aggregate"   0/1   segment reduce as its own HBM-streaming kernel (0, default) or inside node_update (1)
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
- *   "precision"        0/1   0 = exact fp32 MFMA, 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
- *                            fp32 accumulate; ~1e-6 abs deviation on the reference forwards, gate 1e-4) (1) */
+ *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
+ *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
+ *                            2 = mode 1 + the per-edge Eterm table stored as fp16 (2e-6..1.1e-5) (default 2) */
 int ag_set_option(ag_model *m, const char *name, int value);
 
 /* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */

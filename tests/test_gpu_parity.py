@@ -19,6 +19,7 @@ from oracle import ag_oracle as ago
 pytestmark = pytest.mark.gpu
 TOL_FWD = 1e-4        # north_star gate (single forward, identical graphs)
 TOL_TIGHT = 2e-5      # 5x inside the gate: exact-fp32 mode measures ~1e-7..1e-6, split-bf16 mode ~1e-6..6e-6
+TOL_BY_PREC = {"f32": 2e-5, "bf16x3": 2e-5, "fast": 4e-5}   # "fast" adds fp16 Eterm storage: measured 2e-6..1.1e-5
 DEV = "cuda:0"
 
 
@@ -27,7 +28,7 @@ def t(x, dtype=None):
     return r if dtype is None else r.to(dtype)
 
 
-PRECISIONS = {"bf16x3": 1, "f32": 0}   # engine arithmetic modes (include/adaptigraph_hip.h "precision")
+PRECISIONS = {"fast": 2, "bf16x3": 1, "f32": 0}   # engine arithmetic modes (include/adaptigraph_hip.h "precision")
 
 
 @pytest.fixture(scope="module", params=list(PRECISIONS))
@@ -40,7 +41,7 @@ def model(weights, prec):
     return make_model(weights, prec=prec)
 
 
-def make_model(weights, material="rope", decoder_scale=1.0, prec="bf16x3"):
+def make_model(weights, material="rope", decoder_scale=1.0, prec="fast"):
     m = DynamicsPredictor(configs.model_config(), configs.material_config(material), configs.dataset_config(material), DEV)
     sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
     if decoder_scale != 1.0:
@@ -139,11 +140,11 @@ def test_forward_golden(name, weights, prec):
     kw = {material + "_physics_param": t(g["phys"])}
     pos, mot = m(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), action=t(g["action"]), **kw)
     scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
-    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_TIGHT * scale
-    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_TIGHT * scale
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC[prec] * scale
+    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_BY_PREC[prec] * scale
 
 
-def test_forward_dense_onehot_inputs_dropin(weights, model):
+def test_forward_dense_onehot_inputs_dropin(weights, model, prec):
     """model(**graph) with the reference's dict, dense Rr/Rs padded with all-zero rows (pad_torch, utils.py:37-46)."""
     g = load_golden("fwd_rope64")
     B, N = g["attrs"].shape[:2]
@@ -157,8 +158,8 @@ def test_forward_dense_onehot_inputs_dropin(weights, model):
     graph = dict(state=t(g["state"]), attrs=t(g["attrs"]), Rr=Rr, Rs=Rs, p_instance=t(g["p_instance"]),
                  action=t(g["action"]), rope_physics_param=t(g["phys"]), obj_mask=None, p_rigid=torch.zeros(B, 1))
     pos, mot = model(**graph)
-    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_TIGHT
-    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_TIGHT
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC[prec]
+    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_BY_PREC[prec]
 
 
 @pytest.mark.parametrize("material,n_obj,batch,kw", [
@@ -179,11 +180,11 @@ def test_forward_vs_oracle(material, n_obj, batch, kw, weights, prec):
     ref_pos, ref_mot = ago.forward(weights, g["state"], g["attrs"], g["action"], g["p_instance"], g["phys"], n_rel, recv, send)
     kwp = {material + "_physics_param": t(g["phys"])}
     pos, mot = m(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), action=t(g["action"]), **kwp)
-    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_TIGHT
+    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_BY_PREC[prec]
     assert np.abs(pos.cpu().numpy() - ref_pos).max() <= TOL_FWD
 
 
-def test_forward_no_edges_and_single_node(weights, model):
+def test_forward_no_edges_and_single_node(weights, model, prec):
     """Empty adjacency (all particles isolated and masked out of the graph) and a 1-particle cloud."""
     g = synth.make_graph_inputs("rope", 5, 2, seed=1, spacing=10.0)
     N = g["attrs"].shape[1]
@@ -194,7 +195,7 @@ def test_forward_no_edges_and_single_node(weights, model):
     z = np.zeros((2, 1), np.int32)
     ref_pos, ref_mot = ago.forward(weights, g["state"], g["attrs"], g["action"], g["p_instance"], g["phys"],
                                    np.zeros(2, np.int32), z, z)
-    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_TIGHT
+    assert np.abs(mot.cpu().numpy() - ref_mot).max() <= TOL_BY_PREC[prec]
 
 
 def test_forward_is_batch_composition_independent(weights, model):
@@ -222,7 +223,7 @@ def test_forward_translation_invariance(model):
     _, m0 = model(t(g["state"]), *args, **kw)
     shift = torch.tensor([4.0, -2.0, 8.0], device=DEV)
     p1, m1 = model(t(g["state"]) + shift, *args, **kw)
-    assert (m0 - m1).abs().max().item() <= 2e-5
+    assert (m0 - m1).abs().max().item() <= 4e-5
 
 
 # ------------------------------------------------------------------------------------------ rollout drivers
@@ -232,7 +233,7 @@ def test_forward_translation_invariance(model):
 # H3/H4: "gate parity per step on identical graphs; report rollout drift separately").  Exact-fp32 mode matches
 # every golden rollout; split-bf16 mode (forward deviation ~5e-6) flips one neighbour in one granular sample, whose
 # top-20 lists are saturated.  test_rollout_per_step_on_identical_graphs holds that mode to the per-step gate.
-KNOWN_TOPK_FLIPS = {("bf16x3", "dyn_granular80"): (3,)}
+KNOWN_TOPK_FLIPS = {("bf16x3", "dyn_granular80"): (3,), ("fast", "dyn_granular80"): (3,)}
 
 
 def _ppm(material):
@@ -294,7 +295,7 @@ def test_rollout_per_step_on_identical_graphs(weights, material, n_obj):
     trajectory), hence identical graphs; the split-bf16 step must stay within the 1e-4 gate of the exact step."""
     g = synth.make_graph_inputs(material, n_obj, 4, seed=6)
     mm = synth.MATERIALS[material]
-    exact, fast = make_model(weights, material, prec="f32"), make_model(weights, material, prec="bf16x3")
+    exact, fast = make_model(weights, material, prec="f32"), make_model(weights, material, prec="fast")
     thr = aggraph.threshold_sq(mm["radius"], 4, torch.device(DEV), _lib.AG_VARIANT_BATCH)
     one = torch.ones(4, dtype=torch.int32, device=DEV)
     state = t(g["state"])
