@@ -68,34 +68,45 @@ __device__ int prune_topk(float *cd, int *cj, int cnt, int k, int lane)
 
 __global__ __launch_bounds__(256) void select_kernel(AgEdgeArgs a)
 {
-    __shared__ float s_d[4][kCand];
-    __shared__ int s_j[4][kCand];
+    // dynamic LDS: the sample's particle table staged once per block (SoA x|y|z + a 2-bit flag per particle),
+    // then per-wave candidate lists.  Every receiver row of the block re-reads it N/64 times.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y, N = a.N;
+    const int Np = (N + 63) & ~63;
+    float *sx = reinterpret_cast<float *>(smem), *sy = sx + Np, *sz = sy + Np;
+    unsigned char *sf = reinterpret_cast<unsigned char *>(sz + Np);          // bit0 = mask, bit1 = tool
+    float *s_d = reinterpret_cast<float *>(sf + Np);
+    int *s_j = reinterpret_cast<int *>(s_d + 4 * kCand);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *cd = s_d[wave];
-    int *cj = s_j[wave];
+    float *cd = s_d + wave * kCand;
+    int *cj = s_j + wave * kCand;
     const float *pos = a.pos + (size_t)b * a.pos_stride;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    for (int j = threadIdx.x; j < Np; j += 256) {
+        const bool in = j < N;
+        sx[j] = in ? pos[j * 3] : 0.f;
+        sy[j] = in ? pos[j * 3 + 1] : 0.f;
+        sz[j] = in ? pos[j * 3 + 2] : 0.f;
+        sf[j] = in ? (unsigned char)((mk[j] ? 1 : 0) | (tl[j] ? 2 : 0)) : 0;   // padding: invalid sender
+    }
+    __syncthreads();
     const float thr = a.thr_sq[b];
     const int k = N < a.topk ? N : a.topk;
 
     for (int rr = wave; rr < kRowsPerBlock; rr += 4) {
         const int i = blockIdx.x * kRowsPerBlock + rr;
         if (i >= N) break;   // wave-uniform
-        const float xi = pos[i * 3], yi = pos[i * 3 + 1], zi = pos[i * 3 + 2];
-        const bool mi = mk[i], ti = tl[i];
+        const float xi = sx[i], yi = sy[i], zi = sz[i];
+        const bool mi = sf[i] & 1, ti = sf[i] & 2;
         int cnt = 0;
-        for (int j0 = 0; j0 < N; j0 += 64) {
+        for (int j0 = 0; j0 < Np; j0 += 64) {
             const int j = j0 + lane;
-            bool c = false;
-            float d = 0.f;
-            if (j < N) {
-                const float dx = xi - pos[j * 3], dy = yi - pos[j * 3 + 1], dz = zi - pos[j * 3 + 2];
-                d = (dx * dx + dy * dy) + dz * dz;
-                if (!(mi && mk[j])) d = 1e10f;
-                if (ti && tl[j]) d = 1e10f;
-                c = (d - thr) < 0.0f;
-            }
+            const unsigned fj = sf[j];
+            const float dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
+            float d = (dx * dx + dy * dy) + dz * dz;
+            if (!(mi && (fj & 1))) d = 1e10f;          // also kills the j >= N padding (flag 0)
+            if (ti && (fj & 2)) d = 1e10f;
+            const bool c = (d - thr) < 0.0f;
             const unsigned long long bal = __ballot(c);
             if (bal) {
                 if (cnt + 64 > kCand) {   // wave-uniform; keeps the append below in bounds
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(256) void select_kernel(AgEdgeArgs a)
         if (lane == 0) a.deg[row] = cnt;       // provisional when connect_tools_all: finalize_connect_kernel rewrites it
         if (a.connect) {
             // batch_mask (graph.py:123,135): some tool receiver keeps an edge from a non-tool sender
-            const bool hit = ti && lane < cnt && !tl[jsel];
+            const bool hit = ti && lane < cnt && !(sf[jsel < 0 ? 0 : jsel] & 2);
             if (a.variant == 1 && __ballot(hit) && lane == 0) atomicOr(&a.flag[b], 1);
         }
         wave_lds_fence();
@@ -247,7 +258,9 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
 {
     const int rows = a.B * a.N;
     if (a.connect) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
-    hipLaunchKernelGGL(select_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), 0, s, a);
+    const int Np = (a.N + 63) & ~63;
+    const size_t smem = (size_t)Np * 13 + 4 * kCand * 8;
+    hipLaunchKernelGGL(select_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), smem, s, a);
     const int32_t *sel = a.sel0;
     int cap = a.cap0;
     if (a.connect) {
