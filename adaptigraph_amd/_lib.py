@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadaptigraph_hip.so")
+LIB_PATH = os.environ.get("AG_LIB_PATH") or os.path.join(_HERE, "libadaptigraph_hip.so")   # override: kernel A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = ("ag_last_error", "ag_version", "ag_model_create", "ag_model_update_weights", "ag_model_destroy",

@@ -67,6 +67,33 @@ float bf16_to_f32(uint16_t b)
     return x;
 }
 
+// Narrow first layer (fan-in K <= 24, + bias column K): all five out-tiles in ONE chunk image.
+//   F32: [5 tiles][32 rows][32 floats], 16-byte XOR swizzle;  B3: [5 tiles][NU steps][hi|lo][64 lanes][8 bf16]
+void pack_first_layer(std::vector<float> &dst, bool b3, const float *W, int K, int n_out, const float *bias)
+{
+    const size_t base = dst.size();
+    dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
+    float *c = dst.data() + base;
+    uint16_t *cb = reinterpret_cast<uint16_t *>(c);
+    const int NU = (K + 1 + 15) / 16;
+    for (int ti = 0; ti < AG_NT; ++ti)
+        for (int i = 0; i < 32; ++i) {
+            const int o = 32 * ti + i;
+            if (o >= n_out) continue;
+            for (int k = 0; k <= K; ++k) {
+                const float v = k < K ? W[(size_t)o * K + k] : bias[o];
+                if (!b3) {
+                    c[ti * 1024 + i * 32 + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3)] = v;
+                } else {
+                    const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
+                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    cb[((size_t)((ti * NU + u) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    cb[((size_t)((ti * NU + u) * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                }
+            }
+        }
+}
+
 // Append one layer as n_tiles chunk images (AG_CHUNK_FLOATS floats each): input columns [col0, col0+K) of W in
 // image columns [0, K), the bias (if any) in image column K; layout per `b3` as described in ag_common.h.
 void pack_layer(std::vector<float> &dst, bool b3, const float *W, int ld, int col0, int K, int n_out, const float *bias,
@@ -129,14 +156,14 @@ int pack_and_upload(ag_model *m, const float *const *t)
     size_t off[2][4];
     for (int b3 = 0; b3 < 2; ++b3) {
         off[b3][0] = s.size();                                             // node_encode stream
-        pack_layer(s, b3, t[W_PE0], dn, 0, dn, F, t[B_PE0], AG_NT);
+        pack_first_layer(s, b3, t[W_PE0], dn, F, t[B_PE0]);
         pack_layer(s, b3, t[W_PE1], F, 0, F, F, t[B_PE1], AG_NT);
         pack_layer(s, b3, t[W_PE2], F, 0, F, F, t[B_PE2], AG_NT);
         pack_layer(s, b3, t[W_PP], 2 * F, 0, F, F, t[B_PP], AG_NT);        // Pn  = W_pp[:, :F] enc + b_pp
         pack_layer(s, b3, t[W_RP], 3 * F, F, F, F, nullptr, AG_NT);        // Hr  = W_rp[:, F:2F] h
         pack_layer(s, b3, t[W_RP], 3 * F, 2 * F, F, F, nullptr, AG_NT);    // Hs  = W_rp[:, 2F:3F] h
         off[b3][1] = s.size();                                             // edge_encode stream
-        pack_layer(s, b3, t[W_RE0], de, 0, de, F, t[B_RE0], AG_NT);
+        pack_first_layer(s, b3, t[W_RE0], de, F, t[B_RE0]);
         pack_layer(s, b3, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
         pack_layer(s, b3, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
         pack_layer(s, b3, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);        // Eterm = W_rp[:, :F] enc_e + b_rp

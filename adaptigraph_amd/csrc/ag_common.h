@@ -36,8 +36,8 @@ enum { AG_PREC_F32 = 0, AG_PREC_B3 = 1 };
 enum { AG_OK = 0, AG_ERR_ARG = -1, AG_ERR_HIP = -2, AG_ERR_WS = -3, AG_ERR_CONFIG = -4 };
 
 struct AgWeights {           // device pointers into the packed weight streams (float4-aligned)
-    const float4 *node_encode;   // PE0 PE1 PE2 | PPa(+b_pp) | Wr | Ws        30 chunks
-    const float4 *edge_encode;   // RE0 RE1 RE2 | We(+b_rp)                     20 chunks
+    const float4 *node_encode;   // PE0(1 compact chunk) PE1 PE2 | PPa(+b_pp) | Wr | Ws   26 chunks
+    const float4 *edge_encode;   // RE0(1 compact chunk) RE1 RE2 | We(+b_rp)                16 chunks
     const float4 *node_mid;      // PPb | Wr | Ws                               15 chunks
     const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
     // the same streams as split-bf16 fragment images (precision AG_PREC_B3)

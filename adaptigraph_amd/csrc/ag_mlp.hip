@@ -27,6 +27,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef AG_ABL
+#define AG_ABL 0   // timing-only ablation bits for A/B builds (tools/ab_build.sh); 0 in the shipped library
+#endif
+
 namespace {
 
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
@@ -69,21 +73,35 @@ __device__ __forceinline__ void pipe_dma(ChunkPipe &P, int buf)
     P.fetch = P.fetch + 1 == P.total ? 0 : P.fetch + 1;
 }
 
-__device__ __forceinline__ void pipe_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Drain the LDS-DMA of the next chunk before the tile's barrier.  vmcnt retires in order and (on gfx9/CDNA) counts
+// stores too, and the only vector-memory ops a tile issues AFTER its DMA that may still be pending here are the S
+// stores of its own epilogue — so vmcnt(S) waits for the copy without also waiting ~1-2 us for those stores.
+template <int S>
+__device__ __forceinline__ void pipe_wait()
+{
+    static_assert(S >= 0 && S <= 4, "epilogue store count");
+    if (S == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (S == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (S == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (S == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
 
 __device__ __forceinline__ void pipe_start(ChunkPipe &P)
 {
     pipe_dma(P, 0);         // chunk 0
-    pipe_wait();
+    pipe_wait<0>();
     __syncthreads();
 }
 
 // ---- per-tile epilogues (run right after a 32-feature out-tile is finished, so its stores overlap the next
 //      tile's MFMAs instead of piling up behind the layer) -------------------------------------------------
 struct NoEpi {
+    static constexpr int kStores = 0;
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
 };
 struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row = table + row*160 + 4h
+    static constexpr int kStores = 4;
     float *row;
     bool valid;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
@@ -95,6 +113,7 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
     }
 };
 struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
+    static constexpr int kStores = 2;
     _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
     bool valid;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
@@ -109,6 +128,7 @@ struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles]
     }
 };
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
+    static constexpr int kStores = 4;
     float *blk_lane;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
@@ -195,12 +215,46 @@ struct PrecF32 {
             }
             epi(ti, acc);
             sink(ti, acc);
-            pipe_wait();
+            pipe_wait<Epi::kStores>();
             __syncthreads();
             P.buf ^= 1;
         }
     }
+
+    // First layers (fan-in <= 24): all five out-tiles are packed into ONE chunk ([5][32 rows][32 floats], same
+    // 16-byte swizzle), so the layer costs one DMA and one barrier instead of five.
+    template <int K, class Sink>
+    __device__ __forceinline__ static void layer_first(ChunkPipe &P, const Act &in, Sink &&sink)
+    {
+        constexpr int PT = (K + 7) / 8;
+        static_assert(K <= 32, "compact first layer");
+        const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+        const int sw = (i >> 1) & 7;
+        const float *buf = P.lds + P.buf * AG_CHUNK_FLOATS;
+        pipe_dma(P, P.buf ^ 1);
+#pragma unroll
+        for (int ti = 0; ti < AG_NT; ++ti) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < PT; ++q) {
+                const float4 w = *reinterpret_cast<const float4 *>(buf + ti * 1024 + i * 32 + 4 * ((2 * q + h) ^ sw));
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (8 * q + p < K) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[p], in.t[0][4 * q + p], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            sink(ti, acc);
+        }
+        pipe_wait<0>();
+        __syncthreads();
+        P.buf ^= 1;
+    }
 };
+
 
 struct PrecB3 {
     // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
@@ -215,7 +269,7 @@ struct PrecB3 {
                 const float x = v[8 * s + e];
                 const __bf16 hb = (__bf16)x;                 // round-to-nearest-even (v_cvt_pk_bf16_f32)
                 a.hi[2 * ti + s][e] = hb;
-                a.lo[2 * ti + s][e] = (__bf16)(x - (float)hb);
+                a.lo[2 * ti + s][e] = (AG_ABL & 1) ? hb : (__bf16)(x - (float)hb);
             }
     }
 
@@ -224,25 +278,35 @@ struct PrecB3 {
     {
         constexpr int KE = K + (BIAS ? 1 : 0);
         constexpr int NU = (KE + 15) / 16;    // k16-steps per tile
+        constexpr int PF = 2;                 // weight fragments are read PF steps ahead of their MFMAs
         const int lane = threadIdx.x & 63, h = lane >> 5;
+        // The epilogue of tile ti (ReLU, hi/lo split for the next layer, stores) is DEFERRED into tile ti+1, behind
+        // that tile's barrier and fragment prefetch: its ~100 VALU ops then issue in the shadow of tile ti+1's MFMAs
+        // instead of sitting between the last MFMA of a tile and the barrier.
+        f32x16 prev;
+        auto finish = [&](int ti, f32x16 &v) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (AG_ABL & 32) ? v[r] : relu1(v[r]);
+            }
+            if (!(AG_ABL & 8) || v[0] == 1234.5678f) epi(ti, v);   // (ablation keeps the value live: no DCE)
+            sink(ti, v);
+        };
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const bf16x8 *buf = reinterpret_cast<const bf16x8 *>(P.lds + P.buf * AG_CHUNK_FLOATS) + lane;
-            pipe_dma(P, P.buf ^ 1);
+            if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
-            // weight fragments are read two k16-steps ahead of their MFMAs (3 x 32-cycle MFMAs per step do not
-            // cover an LDS round trip on their own)
-            constexpr int PF = 2;
             bf16x8 wq[PF + 1][2];
 #pragma unroll
             for (int u = 0; u < PF && u < NU; ++u) { wq[u][0] = buf[(2 * u) * 64]; wq[u][1] = buf[(2 * u + 1) * 64]; }
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PF < NU ? PF : NU), 0);   // prologue reads first
+            if (ti > 0) finish(ti - 1, prev);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 if (u + PF < NU) {
                     wq[(u + PF) % (PF + 1)][0] = buf[(2 * (u + PF)) * 64];
                     wq[(u + PF) % (PF + 1)][1] = buf[(2 * (u + PF) + 1) * 64];
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);               // reads of step u+PF ...
                 }
                 const bf16x8 wh = wq[u % (PF + 1)][0], wl = wq[u % (PF + 1)][1];
                 bf16x8 xh = in.hi[u], xl = in.lo[u];
@@ -253,20 +317,47 @@ struct PrecB3 {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                   // ... ahead of the 3 MFMAs of step u
             }
-            if (RELU) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
-            }
-            epi(ti, acc);
-            sink(ti, acc);
-            pipe_wait();
-            __syncthreads();
+            prev = acc;
+            if (ti == 0) pipe_wait<0>(); else pipe_wait<Epi::kStores>();
+            if (!(AG_ABL & 2)) __syncthreads();
             P.buf ^= 1;
         }
+        finish(NT - 1, prev);
+    }
+
+    // First layers (fan-in <= 32): the NU k16-steps of all five out-tiles are packed into ONE chunk
+    // ([5 tiles][NU][hi|lo][64 lanes][8 bf16]), one DMA and one barrier for the whole layer.
+    template <int K, class Sink>
+    __device__ __forceinline__ static void layer_first(ChunkPipe &P, const Act &in, Sink &&sink)
+    {
+        constexpr int NU = (K + 15) / 16;
+        static_assert(NU <= 2, "compact first layer");
+        const int lane = threadIdx.x & 63;
+        const bf16x8 *buf = reinterpret_cast<const bf16x8 *>(P.lds + P.buf * AG_CHUNK_FLOATS) + lane;
+        pipe_dma(P, P.buf ^ 1);
+#pragma unroll
+        for (int ti = 0; ti < AG_NT; ++ti) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const bf16x8 wh = buf[((ti * NU + u) * 2) * 64], wl = buf[((ti * NU + u) * 2 + 1) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, in.hi[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in.lo[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in.hi[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            sink(ti, acc);
+        }
+        pipe_wait<0>();
+        __syncthreads();
+        P.buf ^= 1;
     }
 };
+
 
 // layer -> next Act
 template <class Prec, int K, bool RELU, bool BIAS, class Init, class Epi = NoEpi>
@@ -274,6 +365,12 @@ __device__ __forceinline__ void dense(ChunkPipe &P, const typename Prec::Act &in
                                       const Epi &epi = Epi{})
 {
     Prec::template layer<K, AG_NT, RELU, BIAS>(P, in, init, epi, [&](int ti, const f32x16 &v) { Prec::set_tile(out, ti, v); });
+}
+// narrow first layer (ReLU, bias column already in the input features) -> next Act
+template <class Prec, int K>
+__device__ __forceinline__ void dense_first(ChunkPipe &P, const typename Prec::Act &in, typename Prec::Act &out)
+{
+    Prec::template layer_first<K>(P, in, [&](int ti, const f32x16 &v) { Prec::set_tile(out, ti, v); });
 }
 // layer whose output is only stored (by `epi`)
 template <class Prec, int K, bool RELU, bool BIAS, class Init, class Epi>
@@ -381,7 +478,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
-    ChunkPipe P{pick<Prec>(w.node_encode, w.node_encode_b3), 30, 0, 0, lds};
+    ChunkPipe P{pick<Prec>(w.node_encode, w.node_encode_b3), 26, 0, 0, lds};
     pipe_start(P);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -411,7 +508,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
         Prec::set_tile(x, 0, in0);
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)gc * AG_FP + 4 * h;
-        dense<Prec, AG_NODE_IN_MAX - 1, true, false>(P, x, y, ZeroInit{});
+        dense_first<Prec, AG_NODE_IN_MAX>(P, x, y);
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
         dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
@@ -437,13 +534,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
-    ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 20, 0, 0, lds};
+    ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 16, 0, 0, lds};
     pipe_start(P);
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int e = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = e < E;
-        const int r = valid ? a.edge_recv[e] : 0, s = valid ? a.edge_send[e] : 0;
+        const int r = (AG_ABL & 64) ? (e & 1023) : (valid ? a.edge_recv[e] : 0), s = (AG_ABL & 64) ? ((e * 7) & 1023) : (valid ? a.edge_send[e] : 0);
         const int b = r / a.N, ri = r - b * a.N, si = s - b * a.N;
 
         float feat[24];
@@ -488,7 +585,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
-        dense<Prec, AG_EDGE_IN + 1, true, false>(P, x, y, ZeroInit{});
+        dense_first<Prec, AG_EDGE_IN + 1>(P, x, y);
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
         if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
