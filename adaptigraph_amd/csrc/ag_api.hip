@@ -221,6 +221,9 @@ void carve_edges(Carver &c, AgEdgeArgs &a)
     a.deg = c.take<int32_t>(rows);
     a.flag = c.take<int32_t>(a.B);
     a.blk_sum = c.take<int32_t>(rows / 1024 + 2);
+    a.grid_raw = c.take<int32_t>((size_t)a.B * 8);
+    a.cell_start = c.take<int32_t>((size_t)a.B * 8193);
+    a.sorted = c.take<float4>(rows);
 }
 
 void edge_caps(int N, int topk, int connect, int max_tools, int *cap0, int *cap)

@@ -88,6 +88,11 @@ struct AgEdgeArgs {
     int32_t *deg;      // (B*N)
     int32_t *flag;     // (B) connect_tools_all batch_mask
     int32_t *blk_sum;  // scan partials
+    // uniform-grid candidate search (ag_edges.hip: bin_kernel / select_cells_kernel)
+    struct GridParamsPOD { float x0, y0, z0, inv; int nx, ny, nz, total; };
+    void *grid_raw;        // (B) GridParams
+    int32_t *cell_start;   // (B, 8193)
+    float4 *sorted;        // (B, N) x, y, z, bits(j | tool << 30) in cell order
 };
 void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);
 

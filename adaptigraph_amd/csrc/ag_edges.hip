@@ -16,6 +16,7 @@
 //           batch_mask and the tool->tool edges it keeps (graph.py:77-80 vs :134-144)
 //   order : (receiver, sender) ascending == adj_matrix.nonzero() row-major order (graph.py:151)
 #include "ag_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -135,6 +136,278 @@ __global__ __launch_bounds__(256) void select_kernel(AgEdgeArgs a)
     }
 }
 
+__device__ int block_exclusive_scan(int v, int *total)
+{
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+// ---- uniform-grid ("cell list") candidate search -------------------------------------------------------------
+// For N in the thousands the O(N^2) scan above dominates the whole step (cloth-4k: 16.8 M pair tests per graph).
+// bin_kernel sorts the valid particles of a sample into cubic cells of edge >= radius * 1.002 (one workgroup per
+// sample, counting sort in LDS, x fastest so the 3 x-neighbour cells are one contiguous range); select_cells_kernel
+// then tests only the <= 9 ranges around the receiver.  The candidate SET is exactly the in-radius set of the brute
+// force scan (any pair with fp32 d < thr lies in adjacent cells: |dx|/cs <= 0.998 plus < 1e-3 of fp32 rounding in the
+// cell coordinate), the distance arithmetic and the (d, j) ranking are the same code, and the <= k survivors are
+// re-sorted by sender index, so the emitted edge lists are bit-identical (tests compare both paths to the oracle).
+constexpr int kCellMax = 8192;
+
+struct GridParams { float x0, y0, z0, inv; int nx, ny, nz, total; };
+
+__device__ __forceinline__ int cell_coord(float x, float x0, float inv, int n)
+{
+    const int c = (int)((x - x0) * inv);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
+{
+    __shared__ int cnt[kCellMax];
+    __shared__ float red[6][4];
+    __shared__ GridParams G;
+    const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pos = a.pos + (size_t)b * a.pos_stride;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = tid; j < N; j += 256)
+        if (mk[j])
+            for (int c = 0; c < 3; ++c) { const float v = pos[j * 3 + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+        if (lane == 0) { red[c][wave] = lo[c]; red[3 + c][wave] = hi[c]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mn[3], mx[3];
+        for (int c = 0; c < 3; ++c) {
+            mn[c] = fminf(fminf(red[c][0], red[c][1]), fminf(red[c][2], red[c][3]));
+            mx[c] = fmaxf(fmaxf(red[3 + c][0], red[3 + c][1]), fmaxf(red[3 + c][2], red[3 + c][3]));
+            if (!(mx[c] >= mn[c])) { mn[c] = 0.f; mx[c] = 0.f; }     // no valid particle
+        }
+        float cs = sqrtf(a.thr_sq[b]) * 1.002f;
+        if (!(cs > 1e-20f)) cs = 1e-20f;
+        int nx, ny, nz;
+        for (;;) {   // coarsen until the grid fits the LDS histogram (larger cells stay exact, only less selective)
+            const float fx = (mx[0] - mn[0]) / cs, fy = (mx[1] - mn[1]) / cs, fz = (mx[2] - mn[2]) / cs;
+            if (fx < 8000.f && fy < 8000.f && fz < 8000.f) {
+                nx = (int)fx + 1; ny = (int)fy + 1; nz = (int)fz + 1;
+                if ((long long)nx * ny * nz <= kCellMax) break;
+            }
+            cs *= 2.0f;
+        }
+        G.x0 = mn[0]; G.y0 = mn[1]; G.z0 = mn[2]; G.inv = 1.0f / cs; G.nx = nx; G.ny = ny; G.nz = nz; G.total = 0;
+    }
+    __syncthreads();
+    const GridParams g = G;
+    const int ncell = g.nx * g.ny * g.nz;
+    for (int c = tid; c < ncell; c += 256) cnt[c] = 0;
+    __syncthreads();
+    for (int j = tid; j < N; j += 256)
+        if (mk[j]) {
+            const int cid = (cell_coord(pos[j * 3 + 2], g.z0, g.inv, g.nz) * g.ny + cell_coord(pos[j * 3 + 1], g.y0, g.inv, g.ny)) * g.nx +
+                            cell_coord(pos[j * 3], g.x0, g.inv, g.nx);
+            atomicAdd(&cnt[cid], 1);
+        }
+    __syncthreads();
+    // exclusive scan of cnt[0..ncell): thread t owns cells [t*32, t*32+32)
+    int local = 0;
+    for (int c = tid * 32; c < tid * 32 + 32 && c < ncell; ++c) local += cnt[c];
+    int total;
+    int run = block_exclusive_scan(local, &total);
+    int32_t *cs_out = a.cell_start + (size_t)b * (kCellMax + 1);
+    for (int c = tid * 32; c < tid * 32 + 32 && c < ncell; ++c) {
+        const int v = cnt[c];
+        cnt[c] = run;            // becomes the running insertion offset
+        cs_out[c] = run;
+        run += v;
+    }
+    if (tid == 0) { cs_out[ncell] = total; GridParams out = g; out.total = total; reinterpret_cast<GridParams *>(a.grid_raw)[b] = out; }
+    __syncthreads();
+    float4 *sorted = a.sorted + (size_t)b * N;
+    for (int j = tid; j < N; j += 256)
+        if (mk[j]) {
+            const float x = pos[j * 3], y = pos[j * 3 + 1], z = pos[j * 3 + 2];
+            const int cid = (cell_coord(z, g.z0, g.inv, g.nz) * g.ny + cell_coord(y, g.y0, g.inv, g.ny)) * g.nx + cell_coord(x, g.x0, g.inv, g.nx);
+            const int p = atomicAdd(&cnt[cid], 1);
+            sorted[p] = make_float4(x, y, z, __int_as_float(j | (tl[j] ? 0x40000000 : 0)));
+        }
+}
+
+__global__ __launch_bounds__(256) void select_cells_kernel(AgEdgeArgs a)
+{
+    __shared__ float s_d[4][kCand];
+    __shared__ int s_j[4][kCand];
+    const int b = blockIdx.y, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *cd = s_d[wave];
+    int *cj = s_j[wave];
+    const float *pos = a.pos + (size_t)b * a.pos_stride;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    const GridParams g = reinterpret_cast<const GridParams *>(a.grid_raw)[b];
+    const int32_t *cstart = a.cell_start + (size_t)b * (kCellMax + 1);
+    const float4 *sorted = a.sorted + (size_t)b * N;
+    const float thr = a.thr_sq[b];
+    const int k = N < a.topk ? N : a.topk;
+
+    for (int rr = wave; rr < kRowsPerBlock; rr += 4) {
+        const int i = blockIdx.x * kRowsPerBlock + rr;
+        if (i >= N) break;   // wave-uniform
+        const size_t row = (size_t)b * N + i;
+        const bool mi = mk[i], ti = tl[i];
+        int cnt = 0;
+        if (mi) {
+            const float xi = pos[i * 3], yi = pos[i * 3 + 1], zi = pos[i * 3 + 2];
+            const int ix = cell_coord(xi, g.x0, g.inv, g.nx), iy = cell_coord(yi, g.y0, g.inv, g.ny), iz = cell_coord(zi, g.z0, g.inv, g.nz);
+            const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
+            // lanes 0..8 fetch the (dz, dy) neighbour ranges in ONE round trip; the concatenation of the ranges is
+            // then swept 64 candidates at a time (a serial loop over the 9 ranges is a chain of dependent loads)
+            int len = 0, p0 = 0;
+            if (lane < 9) {
+                const int z2 = iz + lane / 3 - 1, y2 = iy + lane % 3 - 1;
+                if (z2 >= 0 && z2 < g.nz && y2 >= 0 && y2 < g.ny) {
+                    const int base = (z2 * g.ny + y2) * g.nx;
+                    p0 = cstart[base + x_lo];
+                    len = cstart[base + x_hi + 1] - p0;
+                }
+            }
+            int incl = len;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            const int total = __shfl(incl, 8);
+            const int excl = incl - len;
+            for (int tb = 0; tb < total; tb += 64) {
+                const int t = tb + lane;
+                int p = -1;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int e_r = __shfl(excl, r), n_r = __shfl(len, r), p_r = __shfl(p0, r);
+                    if (t >= e_r && t < e_r + n_r) p = p_r + (t - e_r);
+                }
+                bool c = false;
+                float d = 0.f;
+                int j = 0;
+                if (p >= 0) {
+                    const float4 sj = sorted[p];
+                    const int w = __float_as_int(sj.w);
+                    j = w & 0x3fffffff;
+                    const float dx = xi - sj.x, dy2 = yi - sj.y, dz2 = zi - sj.z;
+                    d = (dx * dx + dy2 * dy2) + dz2 * dz2;
+                    if (ti && (w & 0x40000000)) d = 1e10f;   // tool-tool (graph.py:118); invalid senders are not binned
+                    c = (d - thr) < 0.0f;
+                }
+                const unsigned long long bal = __ballot(c);
+                if (bal) {
+                    if (cnt + 64 > kCand) cnt = prune_topk(cd, cj, cnt, k, lane);
+                    if (c) {
+                        const int q = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                        cd[q] = d;
+                        cj[q] = j;
+                    }
+                    cnt += __popcll(bal);
+                    wave_lds_fence();
+                }
+            }
+            if (cnt > k) cnt = prune_topk(cd, cj, cnt, k, lane);
+        }
+        // the survivors arrive in cell order: emit them in ascending sender index (k <= 64: one per lane)
+        const int jsel = lane < cnt ? cj[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < cnt; ++t) rank += __shfl(jsel, t) < jsel;
+        if (lane < cnt) a.sel0[row * a.cap0 + rank] = jsel;
+        if (lane == 0) a.deg[row] = cnt;
+        if (a.connect) {
+            const bool hit = ti && lane < cnt && !tl[jsel == 0x7fffffff ? 0 : jsel];
+            if (a.variant == 1 && __ballot(hit) && lane == 0) atomicOr(&a.flag[b], 1);
+        }
+        wave_lds_fence();
+    }
+}
+
+// Lane-per-receiver variant of the cell search for the shipped top-k values: every lane walks the <= 9 cell ranges of
+// its own receiver and keeps its K best (d, j) in registers (compare-exchange insertion), so 64 receivers are in
+// flight per wave instead of one — the wave-per-receiver kernel above is a chain of dependent round trips per row.
+template <int K>
+__global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
+{
+    const int b = blockIdx.y, N = a.N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float *pos = a.pos + (size_t)b * a.pos_stride;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    const GridParams g = reinterpret_cast<const GridParams *>(a.grid_raw)[b];
+    const int32_t *cstart = a.cell_start + (size_t)b * (kCellMax + 1);
+    const float4 *sorted = a.sorted + (size_t)b * N;
+    const float thr = a.thr_sq[b];
+    const size_t row = (size_t)b * N + i;
+    const bool mi = mk[i], ti = tl[i];
+    float bd[K];
+    int bj[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) { bd[s] = 3.0e38f; bj[s] = 0x7fffffff; }
+    int cnt = 0;
+    if (mi) {
+        const float xi = pos[i * 3], yi = pos[i * 3 + 1], zi = pos[i * 3 + 2];
+        const int ix = cell_coord(xi, g.x0, g.inv, g.nx), iy = cell_coord(yi, g.y0, g.inv, g.ny), iz = cell_coord(zi, g.z0, g.inv, g.nz);
+        const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
+        for (int r = 0; r < 9; ++r) {
+            const int z2 = iz + r / 3 - 1, y2 = iy + r % 3 - 1;
+            if (z2 < 0 || z2 >= g.nz || y2 < 0 || y2 >= g.ny) continue;
+            const int base = (z2 * g.ny + y2) * g.nx;
+            const int p1 = cstart[base + x_hi + 1];
+            for (int p = cstart[base + x_lo]; p < p1; ++p) {
+                const float4 sj = sorted[p];
+                const int w = __float_as_int(sj.w);
+                const float dx = xi - sj.x, dy = yi - sj.y, dz = zi - sj.z;
+                float d = (dx * dx + dy * dy) + dz * dz;
+                if (ti && (w & 0x40000000)) d = 1e10f;   // tool-tool (graph.py:118); invalid senders are not binned
+                if ((d - thr) < 0.0f) {
+                    float cdv = d;
+                    int cjv = w & 0x3fffffff;
+#pragma unroll
+                    for (int s = 0; s < K; ++s) {   // keep bd/bj ascending in (d, j); the loser falls through
+                        const bool lt = (cdv < bd[s]) || (cdv == bd[s] && cjv < bj[s]);
+                        const float td = lt ? bd[s] : cdv;
+                        const int tj = lt ? bj[s] : cjv;
+                        bd[s] = lt ? cdv : bd[s];
+                        bj[s] = lt ? cjv : bj[s];
+                        cdv = td;
+                        cjv = tj;
+                    }
+                    cnt = cnt < K ? cnt + 1 : K;
+                }
+            }
+        }
+    }
+    bool hit = false;
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+        if (s < cnt) {
+            int rank = 0;
+#pragma unroll
+            for (int t = 0; t < K; ++t) rank += (t < cnt && bj[t] < bj[s]) ? 1 : 0;
+            a.sel0[row * a.cap0 + rank] = bj[s];        // ascending sender index
+            hit = hit || (ti && !tl[bj[s]]);
+        }
+    a.deg[row] = cnt;
+    if (a.connect && a.variant == 1 && hit) atomicOr(&a.flag[b], 1);   // batch_mask (graph.py:123,135)
+}
+
 // connect_tools_all overrides: merge {kept object senders} with {all tool senders} in ascending order.
 __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
 {
@@ -178,25 +451,6 @@ __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
 // ---- exclusive scan of the per-row degrees -> row_ptr, then COO fill -----------------------------
 constexpr int kScanRows = 1024;   // rows per block (256 threads x 4)
 
-__device__ int block_exclusive_scan(int v, int *total)
-{
-    __shared__ int wsum[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    return base + x - v;
-}
-
 __global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a)
 {
     const int rows = a.B * a.N;
@@ -228,7 +482,7 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(AgEdgeArgs a, int nblk
     if (threadIdx.x == 0) a.row_ptr[a.B * a.N] = carry;
 }
 
-__global__ __launch_bounds__(256) void fill_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
+__global__ __launch_bounds__(256) void rowptr_kernel(AgEdgeArgs a)
 {
     const int rows = a.B * a.N;
     const int r0 = blockIdx.x * kScanRows + threadIdx.x * 4;
@@ -238,18 +492,21 @@ __global__ __launch_bounds__(256) void fill_kernel(AgEdgeArgs a, const int32_t *
     int total;
     int off = a.blk_sum[blockIdx.x] + block_exclusive_scan(s, &total);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int row = r0 + u;
-        if (row < rows) {
-            a.row_ptr[row] = off;
-            const int gbase = (row / a.N) * a.N;   // global id of the graph's node 0
-            for (int t = 0; t < d[u]; ++t) {
-                a.edge_recv[off + t] = row;
-                a.edge_send[off + t] = gbase + sel[(size_t)row * cap + t];
-            }
-            off += d[u];
-        }
-    }
+    for (int u = 0; u < 4; ++u)
+        if (r0 + u < rows) { a.row_ptr[r0 + u] = off; off += d[u]; }
+}
+
+// one thread per (row, slot): coalesced read of the per-row sender lists, near-coalesced COO writes
+__global__ __launch_bounds__(256) void scatter_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rows = (long long)a.B * a.N;
+    if (idx >= rows * cap) return;
+    const int row = (int)(idx / cap), slot = (int)(idx - (long long)row * cap);
+    if (slot >= a.deg[row]) return;
+    const int e = a.row_ptr[row] + slot;
+    a.edge_recv[e] = row;
+    a.edge_send[e] = (row / a.N) * a.N + sel[idx];
 }
 
 }  // namespace
@@ -258,9 +515,20 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
 {
     const int rows = a.B * a.N;
     if (a.connect) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
-    const int Np = (a.N + 63) & ~63;
-    const size_t smem = (size_t)Np * 13 + 4 * kCand * 8;
-    hipLaunchKernelGGL(select_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), smem, s, a);
+    static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
+    const bool cells = force < 0 ? a.N >= 256 : force != 0;
+    if (cells) {
+        hipLaunchKernelGGL(bin_kernel, dim3(a.B), dim3(256), 0, s, a);
+        const dim3 lgrid((a.N + 255) / 256, a.B);
+        if (a.cap0 == 5 && a.topk == 5) hipLaunchKernelGGL(select_lanes_kernel<5>, lgrid, dim3(256), 0, s, a);
+        else if (a.cap0 == 10 && a.topk == 10) hipLaunchKernelGGL(select_lanes_kernel<10>, lgrid, dim3(256), 0, s, a);
+        else if (a.cap0 == 20 && a.topk == 20) hipLaunchKernelGGL(select_lanes_kernel<20>, lgrid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(select_cells_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), 0, s, a);
+    } else {
+        const int Np = (a.N + 63) & ~63;
+        const size_t smem = (size_t)Np * 13 + 4 * kCand * 8;
+        hipLaunchKernelGGL(select_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), smem, s, a);
+    }
     const int32_t *sel = a.sel0;
     int cap = a.cap0;
     if (a.connect) {
@@ -271,5 +539,7 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     const int nblk = (rows + kScanRows - 1) / kScanRows;
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, a, nblk);
-    hipLaunchKernelGGL(fill_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
+    hipLaunchKernelGGL(rowptr_kernel, dim3(nblk), dim3(256), 0, s, a);
+    const long long slots = (long long)rows * cap;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, a, sel, cap);
 }

@@ -100,13 +100,14 @@ struct NoEpi {
     static constexpr int kStores = 0;
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
 };
+// NB: epilogue stores are UNCONDITIONAL (a row past the valid range writes into the table's padding rows, every
+// table is allocated in whole 128-row tiles): pipe_wait<kStores> relies on every wave having issued exactly
+// kStores vector-memory ops after its DMA, whether or not its rows are valid.
 struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row = table + row*160 + 4h
     static constexpr int kStores = 4;
     float *row;
-    bool valid;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
-        if (!valid) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -115,10 +116,8 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
 struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
     static constexpr int kStores = 2;
     _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
-    bool valid;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
-        if (!valid) return;
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
         h8 a, b;
 #pragma unroll
@@ -507,13 +506,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
-        const size_t rowoff = (size_t)gc * AG_FP + 4 * h;
+        const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         dense_first<Prec, AG_NODE_IN_MAX>(P, x, y);
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
         dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
-        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff, valid});  // Hr
-        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff, valid});  // Hs
+        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff});  // Hr
+        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff});  // Hs
     }
 }
 
@@ -589,10 +588,9 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
         if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
-            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) +
-                                                                                   (size_t)(valid ? e : 0) * AG_FP + 16 * h, valid});
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h});
         else
-            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)(valid ? e : 0) * AG_FP + 4 * h, valid});
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)e * AG_FP + 4 * h});
     }
 }
 
@@ -625,13 +623,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
             for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
         }
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
-        const size_t rowoff = (size_t)gc * AG_FP + 4 * h;
+        const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         if (!LAST) {
             dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
-            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff, valid});
-            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff, valid});
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff});
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff});
         } else {
             dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
             dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
