@@ -348,6 +348,16 @@ int ag_model_destroy(ag_model *m)
     return AG_OK;
 }
 
+int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, ag_stream_t stream)
+{
+    if (!x || !y || !out) return fail(AG_ERR_ARG, "ag_chamfer: null argument");
+    if (B < 1 || N < 1 || M < 1) return fail(AG_ERR_ARG, "ag_chamfer: bad sizes B=%d N=%d M=%d", B, N, M);
+    if (ag_launch_chamfer(x, y, B, N, M, y_batched ? 1 : 0, out, static_cast<hipStream_t>(stream)) != 0)
+        return fail(AG_ERR_ARG, "ag_chamfer: N + M = %d exceeds the LDS-resident limit (12800 points)", N + M);
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_set_option(ag_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");

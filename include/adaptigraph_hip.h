@@ -115,6 +115,11 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
                const uint8_t *obj_mask, const float *thr_sq, const int32_t *repeat, float *out_seq,
                float *state_final, void *workspace, size_t workspace_bytes, ag_stream_t stream);
 
+/* chamfer(x, y) of src/planning/losses.py:4-10 — the MPPI error term:
+ *   x (B,N,3) predicted particles, y (B,M,3) if y_batched else (1,M,3) target cloud  ->  out (B)
+ *   out[b] = mean_m min_n ||x[b,n]-y[.,m]|| + mean_n min_m ||x[b,n]-y[.,m]||; N + M <= 12800. */
+int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, ag_stream_t stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
  * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
  * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the

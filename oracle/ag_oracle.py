@@ -231,3 +231,87 @@ def dynamics_masked(weights, task, state_init, state_mask, action, radius=None, 
     seq = _rollout_core(weights, task, states, delta, attrs, p_instance, phys, mask, tool_mask, radius, repeat, n_obj,
                         height, pstep)
     return seq, decoded
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MPPI glue — numpy restatements of src/planning/losses.py, plan.py:27-59 and
+# plan_utils.py:31-39,80-101, pinned to tests/golden/mppi_*.npz.
+# ---------------------------------------------------------------------------------------------------------------
+def chamfer(x, y):
+    """losses.py:4-10: x (B,N,3), y (B|1,M,3) -> (B,)."""
+    x, y = _f32(x), _f32(y)
+    dis = np.sqrt(((x[:, None, :, :] - y[:, :, None, :]) ** 2).sum(-1, dtype=np.float32))       # (B, M, N)
+    return dis.min(2).mean(1, dtype=np.float32) + dis.min(1).mean(1, dtype=np.float32)
+
+
+def box_loss(state, target):
+    """losses.py:26-35."""
+    x, z = state[:, :, 0], state[:, :, 2]
+    dx = np.maximum(target[0, 0] - x, 0) + np.maximum(x - target[0, 1], 0)
+    dz = np.maximum(target[1, 0] - z, 0) + np.maximum(z - target[1, 1], 0)
+    return np.sqrt(dx ** 2 + dz ** 2).mean(1, dtype=np.float32)
+
+
+def _pre_push_states(state_pred, state_init):
+    first = np.broadcast_to(state_init[:, [0, 2]][None, None], (state_pred.shape[0], 1) + state_init[:, [0, 2]].shape)
+    return np.concatenate([first, state_pred[:, :-1][..., [0, 2]]], 1)
+
+
+def rope_penalty(state_pred, action, state_init, sim_real_ratio=10.0):
+    """losses.py:37-48."""
+    d = np.linalg.norm(action[:, :, None, 0:2] - _pre_push_states(state_pred, state_init), axis=-1).min(-1)
+    return np.exp(-np.maximum(d - np.float32(0.02 * sim_real_ratio), 0) * np.float32(100.0)).astype(np.float32)
+
+
+def cloth_penalty(state_pred, action, state_init, sim_real_ratio=10.0):
+    """losses.py:50-64."""
+    d = np.linalg.norm(action[:, :, None, 0:2] - state_init[None, None][..., [0, 2]], axis=-1)
+    dmin = np.maximum(d.min(-1) - np.float32(0.005 * sim_real_ratio), 0)
+    dmax = np.minimum(d.max(-1), np.float32(0.4 * sim_real_ratio))
+    dmax = dmax / dmax.max()
+    return (1.0 - np.exp(-dmin * 100.0) - dmax * 0.2).astype(np.float32)
+
+
+def granular_penalty(state_pred, action, state_init, sim_real_ratio=10.0):
+    """losses.py:66-92."""
+    x0, z0, th = action[:, :, 0], action[:, :, 1], action[:, :, 2]
+    rad = np.float32(0.05 * sim_real_ratio)
+    dx, dz = rad * np.sin(th), -rad * np.cos(th)
+    offs = np.array([-1, -0.75, -0.5, -0.25, 0, 0.25, 0.5, 0.75, 1], np.float32)
+    pts = np.stack([x0[..., None] + offs * dx[..., None], z0[..., None] + offs * dz[..., None]], -1)
+    s2d = _pre_push_states(state_pred, state_init)
+    d = np.linalg.norm(pts[:, :, :, None] - s2d[:, :, None], axis=-1).min(-1).min(-1)
+    return np.exp(-np.maximum(d - np.float32(0.02 * sim_real_ratio), 0) * np.float32(100.0)).astype(np.float32)
+
+
+def running_cost(state, action, state_cur, error_func, penalty_func, bbox):
+    """plan.py:27-59 -> reward (bsz,)."""
+    bsz, L = state.shape[:2]
+    error = error_func(state.reshape(bsz * L, state.shape[2], 3)).reshape(bsz, L)
+    w = 2.0 / (float(error.max()) + 1e-6)
+    pen = penalty_func(state, action, state_cur)
+    lo, hi = state.min(2), state.max(2)
+    m = np.stack([lo[..., 0] - bbox[0, 0], bbox[0, 1] - hi[..., 0], lo[..., 2] - bbox[1, 0], bbox[1, 1] - hi[..., 2]], -1)
+    box = np.exp(-np.maximum(m, 0) * 100.0).max(-1)
+    return (-w * error[:, -1] - 5.0 * pen.mean(1) - 5.0 * box.mean(1)).astype(np.float32)
+
+
+def clip_actions(action, lo, hi):
+    """plan_utils.py:31-39."""
+    out = np.array(action, np.float32)
+    out[..., 2] = ((out[..., 2] + np.float32(np.pi)) % np.float32(2 * np.pi)) - np.float32(np.pi)
+    return np.clip(out, lo, hi)
+
+
+def optimize_action_mppi(act_seqs, reward, reward_weight, lo, hi, push_length):
+    """plan_utils.py:80-101."""
+    z = reward.astype(np.float32) * np.float32(reward_weight)
+    w = np.exp(z - z.max())
+    w = (w / w.sum())[:, None]
+    xs, zs, th, ln = (act_seqs[..., k] for k in range(4))
+    pl = np.float32(push_length)
+    xe, ze = xs - ln * pl * np.cos(th), zs - ln * pl * np.sin(th)
+    x, zz, x_e, z_e = ((w * v).sum(0) for v in (xs, zs, xe, ze))
+    theta = np.arctan2(zz - z_e, x - x_e)
+    length = np.hypot(x_e - x, z_e - zz) / pl
+    return clip_actions(np.stack([x, zz, theta, length], -1), lo, hi)

@@ -234,14 +234,68 @@ def gen_weights(R):
             assert all(np.array_equal(ref[k], sd[k]) for k in sd), material
 
 
+# ------------------------------------------------------------------ MPPI glue ("next" row n1)
+def gen_mppi(R):
+    import contextlib
+    import io
+    L = R.losses
+    for material, dyn in (("rope", "dyn_rope60"), ("rope", "dyn_rope60_look2"), ("granular", "dyn_granular80"), ("cloth", "dyn_cloth81")):
+        g = np.load(os.path.join(OUT, dyn + ".npz"))
+        _, plan = load_cfg(material)
+        ratio = plan["sim_real_ratio"]
+        state_seqs, action, state_cur = t(g["state_seqs"]), t(g["action"]), t(g["state"])
+        bsz, nl, n, _ = state_seqs.shape
+        rng = np.random.default_rng(31)
+        target = (g["state"][rng.choice(n, 40, replace=False)] + rng.normal(0, 0.05, (40, 3))).astype(np.float32)
+        lo, hi = g["state"].min(0), g["state"].max(0)
+        box = np.array([[lo[0] + 0.2, hi[0] - 0.1], [lo[2] - 0.1, hi[2] + 0.3]], np.float32)
+        bbox = np.array([[lo[0] - 0.5, hi[0] + 0.5], [lo[2] - 0.5, hi[2] + 0.5]], np.float64)
+        flat = state_seqs.reshape(bsz * nl, n, 3)
+        out = dict(material=np.array(material), state_seqs=g["state_seqs"], action=g["action"], state_cur=g["state"],
+                   target=target, box=box, bbox=bbox, sim_real_ratio=np.float64(ratio),
+                   chamfer=L.chamfer(flat, t(target)[None]).numpy(), box_loss=L.box_loss(flat, t(box)).numpy())
+        pen = {"rope": L.rope_penalty, "granular": L.granular_penalty, "cloth": L.cloth_penalty}[material]
+        out["penalty"] = pen(state_seqs, action, state_cur, sim_real_ratio=ratio).numpy()
+        from functools import partial
+        for crit_name, crit in (("chamfer", partial(L.chamfer, y=t(target)[None])), ("box", partial(L.box_loss, target=t(box)))):
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = R.running_cost(state_seqs, action, state_cur, error_func=crit,
+                                   penalty_func=partial(pen, sim_real_ratio=ratio), bbox=bbox)
+            out["reward_" + crit_name] = r["reward_seqs"].numpy()
+        # MPPI update on these rewards (plan_utils.py:80-101) with the task's limits / weights
+        lim_lo, lim_hi = t(np.array(plan["action_lower_lim"], np.float32)), t(np.array(plan["action_upper_lim"], np.float32))
+        upd = R.plan_utils.optimize_action_mppi(action, t(out["reward_chamfer"]), reward_weight=plan["reward_weight"],
+                                                action_lower_lim=lim_lo, action_upper_lim=lim_hi, push_length=plan["push_length"])
+        out.update(lim_lo=lim_lo.numpy(), lim_hi=lim_hi.numpy(), reward_weight=np.float64(plan["reward_weight"]),
+                   push_length=np.float64(plan["push_length"]), mppi_act_seq=upd.numpy())
+        save("mppi_" + dyn[4:], **out)
+
+    # action sampling (plan_utils.py:35-77): CPU torch RNG under a fixed seed is part of the contract we mirror
+    _, plan = load_cfg("rope")
+    lim_lo, lim_hi = t(np.array(plan["action_lower_lim"], np.float32)), t(np.array(plan["action_upper_lim"], np.float32))
+    act_seq = t(np.array([[-2.0, 1.0, 0.5, 8.0], [-1.0, 0.5, -1.0, 6.0]], np.float32))
+    outs = {}
+    for it in (0, 1):
+        torch.manual_seed(1234)
+        outs[f"samples_it{it}"] = R.plan_utils.sample_action_seq(act_seq, lim_lo, lim_hi, 16, "cpu", iter_index=it,
+                                                                  noise_level=plan["noise_level"], push_length=plan["push_length"]).numpy()
+    raw = t(np.array([[1.0, 9.0, 4.0, 20.0], [-9.0, -9.0, -7.0, 1.0], [-1.0, 1.0, 3.2, 7.0]], np.float32))
+    save("mppi_sampling", act_seq=act_seq.numpy(), lim_lo=lim_lo.numpy(), lim_hi=lim_hi.numpy(), seed=np.int64(1234),
+         noise_level=np.float64(plan["noise_level"]), push_length=np.float64(plan["push_length"]),
+         clip_in=raw.numpy(), clip_out=R.plan_utils.clip_actions(raw, lim_lo, lim_hi).numpy(), **outs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "mppi":
+        return gen_mppi(R)
     gen_weights(R)
     gen_edges(R)
     gen_forward(R)
     gen_rollout(R)
+    gen_mppi(R)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,16 @@ def import_reference():
     from dynamics.utils import truncate_graph, pad_torch
     from planning.forward_dynamics import dynamics, dynamics_masked
     from planning.plan_utils import decode_action
+    # planning glue ("next" row n1): plan.py pulls in robot / perception / open3d modules at import time that
+    # running_cost never touches -> stub them; planner.py and losses.py import cleanly.
+    for n in ("open3d", "planning.real_world.real_env", "planning.perception", "planning.physics_param_optimizer"):
+        if n not in sys.modules:
+            _stub(n, RealEnv=None, PerceptionModule=None, get_state_cur=None, PhysicsParamOnlineOptimizer=None)
+    from planning import losses, plan_utils
+    from planning.plan import running_cost
+    from planning.real_world.planner import Planner
     return types.SimpleNamespace(
+        losses=losses, plan_utils=plan_utils, running_cost=running_cost, Planner=Planner,
         DynamicsPredictor=DynamicsPredictor,
         construct_edges_from_states=construct_edges_from_states,
         construct_edges_from_states_batch=construct_edges_from_states_batch,
