@@ -52,6 +52,9 @@ int ag_launch_chamfer(const float *x, const float *y, int B, int N, int M, int y
 {
     const size_t smem = (size_t)3 * (N + M) * sizeof(float);
     if (smem > 150 * 1024) return -1;
+    if (smem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return -2;
     hipLaunchKernelGGL(chamfer_kernel, dim3(B), dim3(256), smem, s, x, y, N, M, y_batched, out);
     return 0;
 }

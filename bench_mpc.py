@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Side benchmark for BASELINE configs[4]: "MPC planning loop: 1024 sampled action sequences x 15-step rollout on
+rope, per-iteration wall-clock".  (bench.py stays the driver's headline line; this one measures the "next" row n1.)
+
+    python bench_mpc.py --gpus 1 --steps 5 --warmup 2 [--particles 1000] [--samples 1024] [--push-steps 15]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench_mpc.py --gpus N ...
+
+One "step" = one MPPI iteration exactly as planner.py's trajectory_optimization_mppi runs it: sample `--samples`
+action sequences around the current one, roll every one of them out (`--push-steps` model steps: edge rebuild + GNN
+forward + tool update each), chamfer cost to the target + push-start penalty + workspace-box penalty, softmax
+update.  Strong scaling: the samples shard across ranks, one RCCL all-gather of the predicted states, every rank
+evaluates the (cheap) cost and update redundantly.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+from functools import partial
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from adaptigraph_amd import _lib, configs, losses, mpc, synth          # noqa: E402
+from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=1000)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--push-steps", type=int, default=15)
+    ap.add_argument("--precision", default="fast", choices=["f32", "bf16x3", "fast"])
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_mpc.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.lib()
+
+    mat = "rope"
+    task = configs.task_config(mat)
+    # every sampled push is exactly --push-steps long so an iteration is a fixed amount of work
+    lo = np.array(task["action_lower_lim"], np.float32)
+    hi = np.array(task["action_upper_lim"], np.float32)
+    lo[3], hi[3] = a.push_steps, a.push_steps + 0.5
+    state, act = synth.make_mpc_inputs(mat, a.particles, 1, seed=0, len_lo=a.push_steps, len_hi=a.push_steps + 0.4,
+                                       spacing=0.1 if a.particles >= 500 else 0.2)
+    target = (state + np.array([0.4, 0.0, 0.3], np.float32)).astype(np.float32)
+    bbox = np.array([[state[:, 0].min() - 5, state[:, 0].max() + 5], [state[:, 2].min() - 5, state[:, 2].max() + 5]])
+    g = torch.Generator().manual_seed(0)
+    model = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), dev)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
+    model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[a.precision])
+    ppm = configs.ppm_optimizer_stub(mat)
+    ppm.physics_param = {mat: torch.tensor([0.5], device=dev)}
+    state_t, target_t = torch.from_numpy(state).to(dev), torch.from_numpy(target).to(dev)
+    planner = mpc.MPPIPlanner(model, dev, ppm, partial(losses.chamfer, y=target_t[None]),
+                              partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
+                              n_sample=a.samples, n_update_iter=1, rollout_best=False)
+    act_seq = torch.from_numpy(act[0]).to(dev)
+
+    def one_iteration(seq, it):
+        torch.manual_seed(1234 + it)                      # same samples on every rank (they are sharded by index)
+        samples = planner.sample(seq, 1)                  # iter_index > 0: perturb around the current sequence
+        new_seq, reward, _ = planner.step(state_t, samples)
+        return new_seq, reward
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    seq = act_seq
+    for i in range(a.warmup):
+        seq, _ = one_iteration(seq, i)
+    fence()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    import time
+    w0 = time.perf_counter()
+    for i in range(a.steps):
+        seq, reward = one_iteration(seq, a.warmup + i)
+    fence()
+    ms = (time.perf_counter() - w0) * 1e3
+    tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ms = float(tt.item())
+    if rank == 0:
+        per_it = ms / a.steps
+        print(json.dumps({
+            "metric": "MPPI iteration wall-clock (sample + rollout + cost + update)", "value": round(per_it, 3), "unit": "ms",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per_it, 3),
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "graph_steps_per_s": round(a.samples * a.push_steps / per_it * 1e3, 1),
+            "config": {"workload": f"rope-{a.particles}+1 MPPI: {a.samples} samples x {a.push_steps}-step rollout, chamfer "
+                                   f"cost to a {a.particles}-point target", "samples": a.samples, "push_steps": a.push_steps,
+                       "particles": a.particles, "parallelism": f"samples/{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
