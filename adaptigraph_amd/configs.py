@@ -31,20 +31,22 @@ def dataset_config(material, n_his=4):
     return {"data_name": material, "materials": [material], "n_his": n_his, "n_future": 3}
 
 
-_TASK_COMMON = dict(sim_real_ratio=10, max_n=1, max_nobj=200, max_nR=2000, n_his=4, n_look_ahead=1)
+_TASK_COMMON = dict(sim_real_ratio=10, max_n=1, max_nobj=200, max_nR=2000, n_his=4, n_look_ahead=1, noise_level=1.0,
+                    reward_weight=500.0)
 TASK_CONFIG = {   # config/planning/{rope,granular,cloth}.yaml
     "rope": dict(_TASK_COMMON, material="rope", material_indices={"rope": 0}, material_dims={"rope": 1},
-                 adj_thresh=0.50, eef_num=1, topk=10, connect_tools_all=False, push_length=0.1,
+                 adj_thresh=0.50, fps_radius=0.20, eef_num=1, topk=10, connect_tools_all=False, push_length=0.1,
                  pusher_points=[[0.0, 0.0, 0.12]], gripper_enable=False,
                  action_lower_lim=[-4.5, -2.5, -3.14, 5], action_upper_lim=[0.0, 4.5, 3.14, 15]),
     "granular": dict(_TASK_COMMON, material="granular", material_indices={"granular": 0},
-                     material_dims={"granular": 1}, adj_thresh=0.40, eef_num=5, topk=20, connect_tools_all=False,
+                     material_dims={"granular": 1}, adj_thresh=0.40, fps_radius=0.20, eef_num=5,
+                     topk=20, connect_tools_all=False,
                      push_length=0.2, gripper_enable=False,
                      pusher_points=[[0.0, 0.0, 0.1], [0.0, 0.05, 0.1], [0.0, 0.025, 0.1], [0.0, -0.025, 0.1],
                                     [0.0, -0.05, 0.1]],
                      action_lower_lim=[-4.5, -2.5, -3.14, 2], action_upper_lim=[0.0, 4.5, 3.14, 10]),
     "cloth": dict(_TASK_COMMON, material="cloth", material_indices={"cloth": 0}, material_dims={"cloth": 1},
-                  adj_thresh=0.75, eef_num=1, topk=5, connect_tools_all=True, push_length=0.1,
+                  adj_thresh=0.75, fps_radius=0.30, eef_num=1, topk=5, connect_tools_all=True, push_length=0.1,
                   pusher_points=[[0.0, 0.0, 0.170]], gripper_enable=True,
                   action_lower_lim=[-4.5, -2.5, -3.14, 2], action_upper_lim=[0.0, 4.5, 3.14, 10]),
 }

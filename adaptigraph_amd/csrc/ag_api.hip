@@ -348,14 +348,27 @@ int ag_model_destroy(ag_model *m)
     return AG_OK;
 }
 
-int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, ag_stream_t stream)
+static int chamfer_common(const char *who, const float *x, const uint8_t *xm, const float *y, const uint8_t *ym, int B, int N, int M,
+                          int y_batched, float *out, ag_stream_t stream)
 {
-    if (!x || !y || !out) return fail(AG_ERR_ARG, "ag_chamfer: null argument");
-    if (B < 1 || N < 1 || M < 1) return fail(AG_ERR_ARG, "ag_chamfer: bad sizes B=%d N=%d M=%d", B, N, M);
-    if (ag_launch_chamfer(x, y, B, N, M, y_batched ? 1 : 0, out, static_cast<hipStream_t>(stream)) != 0)
-        return fail(AG_ERR_ARG, "ag_chamfer: N + M = %d exceeds the LDS-resident limit (12800 points)", N + M);
+    if (!x || !y || !out) return fail(AG_ERR_ARG, "%s: null argument", who);
+    if (B < 1 || N < 1 || M < 1) return fail(AG_ERR_ARG, "%s: bad sizes B=%d N=%d M=%d", who, B, N, M);
+    if (ag_launch_chamfer(x, y, xm, ym, B, N, M, y_batched ? 1 : 0, out, static_cast<hipStream_t>(stream)) != 0)
+        return fail(AG_ERR_ARG, "%s: N + M = %d exceeds the LDS-resident limit (12800 points)", who, N + M);
     AG_HIP(hipGetLastError());
     return AG_OK;
+}
+
+int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, ag_stream_t stream)
+{
+    return chamfer_common("ag_chamfer", x, nullptr, y, nullptr, B, N, M, y_batched, out, stream);
+}
+
+int ag_chamfer_masked(const float *x, const uint8_t *x_mask, const float *y, const uint8_t *y_mask, int B, int N, int M,
+                      int y_batched, float *out, ag_stream_t stream)
+{
+    if (!x_mask || !y_mask) return fail(AG_ERR_ARG, "ag_chamfer_masked: null mask");
+    return chamfer_common("ag_chamfer_masked", x, x_mask, y, y_mask, B, N, M, y_batched, out, stream);
 }
 
 int ag_set_option(ag_model *m, const char *name, int value)

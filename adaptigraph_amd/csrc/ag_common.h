@@ -107,4 +107,5 @@ struct AgStepArgs {
     float raise;              // gripper raise (0 when disabled)
 };
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s);
-int ag_launch_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, hipStream_t s);
+int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
+                      int y_batched, float *out, hipStream_t s);

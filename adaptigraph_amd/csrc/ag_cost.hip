@@ -9,52 +9,70 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void chamfer_kernel(const float *x, const float *y, int N, int M, int y_batched, float *out)
+// xmask / ymask: optional per-point validity (u8, (B,N) / (By,M)); masked-out points take no part in either direction —
+// this is mean_chamfer's `state[i][mask[i]]` compaction (losses.py:12-24) without the per-sample host loop.  Invalid
+// points are parked at +inf in LDS (their squared distance to anything finite is +inf, so no min ever picks them) and
+// skipped as query points.  A sample with no valid point on either side yields NaN (the reference raises there).
+__global__ __launch_bounds__(256) void chamfer_kernel(const float *x, const float *y, const unsigned char *xmask,
+                                                      const unsigned char *ymask, int N, int M, int y_batched, float *out)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float red[2][4];
+    __shared__ float red[4][4];
     float *sx = sm, *sy = sm + 3 * N;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)(y_batched ? b : 0) * M * 3;
-    for (int i = tid; i < 3 * N; i += 256) sx[i] = xb[i];
-    for (int i = tid; i < 3 * M; i += 256) sy[i] = yb[i];
+    const int by = y_batched ? b : 0;
+    const float *xb = x + (size_t)b * N * 3, *yb = y + (size_t)by * M * 3;
+    const unsigned char *xm = xmask ? xmask + (size_t)b * N : nullptr, *ym = ymask ? ymask + (size_t)by * M : nullptr;
+    for (int i = tid; i < 3 * N; i += 256) sx[i] = (xm && !xm[i / 3]) ? INFINITY : xb[i];
+    for (int i = tid; i < 3 * M; i += 256) sy[i] = (ym && !ym[i / 3]) ? INFINITY : yb[i];
     __syncthreads();
-    float s_y = 0.f, s_x = 0.f;
+    float s_y = 0.f, s_x = 0.f, c_y = 0.f, c_x = 0.f;
     for (int m = tid; m < M; m += 256) {          // for every target point: nearest particle
         const float a0 = sy[3 * m], a1 = sy[3 * m + 1], a2 = sy[3 * m + 2];
+        if (a0 == INFINITY) continue;
         float best = INFINITY;
         for (int n = 0; n < N; ++n) {
             const float d0 = sx[3 * n] - a0, d1 = sx[3 * n + 1] - a1, d2 = sx[3 * n + 2] - a2;
             best = fminf(best, (d0 * d0 + d1 * d1) + d2 * d2);
         }
         s_y += sqrtf(best);
+        c_y += 1.f;
     }
     for (int n = tid; n < N; n += 256) {          // for every particle: nearest target point
         const float a0 = sx[3 * n], a1 = sx[3 * n + 1], a2 = sx[3 * n + 2];
+        if (a0 == INFINITY) continue;
         float best = INFINITY;
         for (int m = 0; m < M; ++m) {
             const float d0 = a0 - sy[3 * m], d1 = a1 - sy[3 * m + 1], d2 = a2 - sy[3 * m + 2];
             best = fminf(best, (d0 * d0 + d1 * d1) + d2 * d2);
         }
         s_x += sqrtf(best);
+        c_x += 1.f;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s_y += __shfl_xor(s_y, o); s_x += __shfl_xor(s_x, o); }
-    if (lane == 0) { red[0][wave] = s_y; red[1][wave] = s_x; }
+    for (int o = 32; o > 0; o >>= 1) {
+        s_y += __shfl_xor(s_y, o); s_x += __shfl_xor(s_x, o);
+        c_y += __shfl_xor(c_y, o); c_x += __shfl_xor(c_x, o);
+    }
+    if (lane == 0) { red[0][wave] = s_y; red[1][wave] = s_x; red[2][wave] = c_y; red[3][wave] = c_x; }
     __syncthreads();
-    if (tid == 0)
-        out[b] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)M + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)N;
+    if (tid == 0) {
+        const float ny = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]), nx = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+        const float v = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / ny + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / nx;
+        out[b] = (nx > 0.f && ny > 0.f) ? v : NAN;
+    }
 }
 
 }  // namespace
 
-int ag_launch_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, hipStream_t s)
+int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
+                      int y_batched, float *out, hipStream_t s)
 {
     const size_t smem = (size_t)3 * (N + M) * sizeof(float);
     if (smem > 150 * 1024) return -1;
     if (smem > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return -2;
-    hipLaunchKernelGGL(chamfer_kernel, dim3(B), dim3(256), smem, s, x, y, N, M, y_batched, out);
+    hipLaunchKernelGGL(chamfer_kernel, dim3(B), dim3(256), smem, s, x, y, xmask, ymask, N, M, y_batched, out);
     return 0;
 }

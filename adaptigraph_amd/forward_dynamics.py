@@ -89,7 +89,11 @@ def _physics(ppm_optimizer, physics_param, bsz, device):
     material = ppm_optimizer.material
     dims = ppm_optimizer.material_dims
     assert len(dims) == 1 and material in dims, "Only support single material."
-    return physics_param[material].to(device, torch.float32)[None].repeat(bsz, 1)
+    p = physics_param[material].to(device, torch.float32)
+    if p.dim() == 2:      # extension over the reference: one parameter vector PER SAMPLE (batched sys-id sweeps)
+        assert p.shape[0] == bsz, f"per-sample physics_param needs {bsz} rows, got {p.shape[0]}"
+        return p.contiguous()
+    return p[None].repeat(bsz, 1)
 
 
 @torch.no_grad()

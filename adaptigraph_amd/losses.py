@@ -26,6 +26,29 @@ def chamfer(x, y):
     return out
 
 
+def mean_chamfer_device(state_pred, state_real, state_pred_mask, state_real_mask):
+    """Per-sample chamfer over the masked-in points of two padded clouds, one launch for the whole batch -> (bsz,) tensor."""
+    _require_gpu(state_pred, "state_pred")
+    dev = state_pred.device
+    x = state_pred.contiguous().float()
+    y = state_real.to(dev).contiguous().float()
+    xm = state_pred_mask.to(dev).ne(0).to(torch.uint8).contiguous()
+    ym = state_real_mask.to(dev).ne(0).to(torch.uint8).contiguous()
+    assert x.dim() == 3 and y.dim() == 3 and y.shape[0] == x.shape[0] and xm.shape == x.shape[:2] and ym.shape == y.shape[:2]
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ag_chamfer_masked(x.data_ptr(), xm.data_ptr(), y.data_ptr(), ym.data_ptr(), x.shape[0], x.shape[1],
+                                          y.shape[1], 1, out.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "ag_chamfer_masked")
+    return out
+
+
+def mean_chamfer(state_pred, state_real, state_pred_mask, state_real_mask):
+    """losses.py:12-24: numpy (bsz,) of chamfer(state_pred[i][mask_i], state_real[i][mask_i]); the reference loops over
+    the batch with one `.item()` sync per sample, here it is one kernel and one copy."""
+    return mean_chamfer_device(state_pred, state_real, state_pred_mask, state_real_mask).double().cpu().numpy()
+
+
 def box_loss(state, target):
     """state (B,N,3), target [[xmin,xmax],[zmin,zmax]] -> (B,) mean distance to the box in the x-z plane (losses.py:26-35)."""
     x, z = state[:, :, 0], state[:, :, 2]

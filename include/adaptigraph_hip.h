@@ -120,6 +120,12 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
  *   out[b] = mean_m min_n ||x[b,n]-y[.,m]|| + mean_n min_m ||x[b,n]-y[.,m]||; N + M <= 12800. */
 int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batched, float *out, ag_stream_t stream);
 
+/* mean_chamfer(state_pred, state_real, pred_mask, real_mask) of src/planning/losses.py:12-24 — the sys-id objective
+ *  — for the whole batch in one launch: chamfer over the points whose mask byte is non-zero.
+ *   x (B,N,3), x_mask (B,N) u8, y (B|1,M,3), y_mask (B|1,M) u8  ->  out (B); NaN where a side has no valid point. */
+int ag_chamfer_masked(const float *x, const uint8_t *x_mask, const float *y, const uint8_t *y_mask, int B, int N, int M,
+                      int y_batched, float *out, ag_stream_t stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
  * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
  * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the

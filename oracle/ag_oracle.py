@@ -315,3 +315,22 @@ def optimize_action_mppi(act_seqs, reward, reward_weight, lo, hi, push_length):
     theta = np.arctan2(zz - z_e, x - x_e)
     length = np.hypot(x_e - x, z_e - zz) / pl
     return clip_actions(np.stack([x, zz, theta, length], -1), lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sys-id objective: losses.py:12-24 + physics_param_optimizer.py:178-226, pinned to
+# tests/golden/sysid_*.npz.
+# ---------------------------------------------------------------------------------------------------------------
+def mean_chamfer(state_pred, state_real, pred_mask, real_mask):
+    return np.array([float(chamfer(state_pred[i][pred_mask[i].astype(bool)][None], state_real[i][real_mask[i].astype(bool)][None])[0])
+                     for i in range(state_pred.shape[0])], np.float64)
+
+
+def dynamics_error(weights, task, phys_value, state_init_list, state_real_list, actions):
+    """-> (mean error, per-interaction errors, predicted padded states)."""
+    mx, n = task["max_nobj"], len(actions)
+    pad = lambda L: np.stack([np.pad(_f32(x), ((0, mx - len(x)), (0, 0))) for x in L])
+    msk = lambda L: np.stack([np.arange(mx) < len(x) for x in L])
+    seq, _ = dynamics_masked(weights, task, pad(state_init_list), msk(state_init_list), np.stack(actions), phys_value=phys_value)
+    per = mean_chamfer(seq, pad(state_real_list), msk(state_init_list), msk(state_real_list))
+    return float(per.mean()), per, seq

@@ -285,17 +285,54 @@ def gen_mppi(R):
          clip_in=raw.numpy(), clip_out=R.plan_utils.clip_actions(raw, lim_lo, lim_hi).numpy(), **outs)
 
 
+# ------------------------------------------------------------------ sys-id objective ("next" row n2)
+def gen_sysid(R):
+    P = R.physics_param_optimizer
+    for material, n0, kw in (("rope", 40, dict(spacing=0.1)), ("granular", 60, {})):
+        _, plan = load_cfg(material)
+        plan = dict(plan, max_nobj=72)                 # keep the CPU reference run and the fixture small
+        model = build_model(R, material)
+        ppm = ppm_namespace(plan)
+        ppm.model, ppm.device = model, "cpu"
+        rng = np.random.default_rng(77)
+        inits, reals, acts = [], [], []
+        for b in range(3):
+            nb = n0 - 4 * b
+            obj, a = synth.make_mpc_inputs(material, nb, 1, seed=40 + b, len_lo=1, len_hi=4, **kw)
+            inits.append(obj.astype(np.float32))
+            keep = np.sort(rng.choice(nb, nb - 1 - b, replace=False))      # the "observed" cloud has a different point count
+            reals.append((obj[keep] + rng.normal(0, 0.03, (len(keep), 3))).astype(np.float32))
+            acts.append(a[0, 0])
+        out = {}
+        for i, pv in enumerate((0.2, 0.5, 0.9)):
+            out[f"error_p{i}"] = np.float64(P.dynamics_error([pv], ppm, inits, reals, acts))
+        # per-sample values behind the mean at phys 0.5 (mean_chamfer on the padded tensors)
+        mx = plan["max_nobj"]
+        pad = lambda L: np.stack([np.pad(x, ((0, mx - len(x)), (0, 0))) for x in L])
+        msk = lambda L: np.stack([np.arange(mx) < len(x) for x in L])
+        o = R.dynamics_masked(t(pad(inits)), t(msk(inits)), t(np.stack(acts)), model, "cpu", ppm,
+                              physics_param={material: torch.tensor([0.5])})
+        per = R.losses.mean_chamfer(o["state_seqs"].detach(), t(pad(reals)), t(msk(inits)), t(msk(reals)))
+        save("sysid_" + material, material=np.array(material), max_nobj=np.int64(mx), phys=np.array([0.2, 0.5, 0.9]),
+             n_init=np.array([len(x) for x in inits]), n_real=np.array([len(x) for x in reals]),
+             state_init=pad(inits), state_real=pad(reals), action=np.stack(acts), state_pred_p1=o["state_seqs"].numpy(),
+             chamfer_p1=np.asarray(per, np.float64), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "mppi":
         return gen_mppi(R)
+    if len(sys.argv) > 1 and sys.argv[1] == "sysid":
+        return gen_sysid(R)
     gen_weights(R)
     gen_edges(R)
     gen_forward(R)
     gen_rollout(R)
     gen_mppi(R)
+    gen_sysid(R)
 
 
 if __name__ == "__main__":

@@ -39,14 +39,21 @@ def import_reference():
     from planning.plan_utils import decode_action
     # planning glue ("next" row n1): plan.py pulls in robot / perception / open3d modules at import time that
     # running_cost never touches -> stub them; planner.py and losses.py import cleanly.
-    for n in ("open3d", "planning.real_world.real_env", "planning.perception", "planning.physics_param_optimizer"):
+    for n in ("open3d", "planning.real_world.real_env", "planning.perception"):
         if n not in sys.modules:
-            _stub(n, RealEnv=None, PerceptionModule=None, get_state_cur=None, PhysicsParamOnlineOptimizer=None)
-    from planning import losses, plan_utils
+            _stub(n, RealEnv=None, PerceptionModule=None, get_state_cur=None)
+    # physics_param_optimizer.py imports cma / skopt (absent) for its black-box search; dynamics_error (row n2) needs neither
+    for n in ("cma", "skopt", "skopt.learning", "skopt.learning.gaussian_process", "skopt.learning.gaussian_process.kernels",
+              "skopt.utils"):
+        if n not in sys.modules:
+            _stub(n, gp_minimize=None, WhiteKernel=None, RBF=None, Matern=None, GaussianProcessRegressor=None,
+                  expected_minimum=None)
+    from planning import losses, plan_utils, physics_param_optimizer
     from planning.plan import running_cost
     from planning.real_world.planner import Planner
     return types.SimpleNamespace(
         losses=losses, plan_utils=plan_utils, running_cost=running_cost, Planner=Planner,
+        physics_param_optimizer=physics_param_optimizer,
         DynamicsPredictor=DynamicsPredictor,
         construct_edges_from_states=construct_edges_from_states,
         construct_edges_from_states_batch=construct_edges_from_states_batch,
