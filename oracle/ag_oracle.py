@@ -334,3 +334,29 @@ def dynamics_error(weights, task, phys_value, state_init_list, state_real_list, 
     seq, _ = dynamics_masked(weights, task, pad(state_init_list), msk(state_init_list), np.stack(actions), phys_value=phys_value)
     per = mean_chamfer(seq, pad(state_real_list), msk(state_init_list), msk(state_real_list))
     return float(per.mean()), per, seq
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Open-loop evaluation rollout: the per-graph loop of src/dynamics/rollout/rollout.py:66-141 for a
+# given start graph and frame schedule, pinned to tests/golden/evalrollout_rope.npz.
+# ---------------------------------------------------------------------------------------------------------------
+def eval_rollout(weights, graph, fps_idx, schedule, eef_pos, obj_pos, adj_thresh, topk, connect_tool_all, phys):
+    state = _f32(graph["state"])[None]
+    action = _f32(graph["action"])[None]
+    attrs, p_inst = _f32(graph["attrs"])[None], _f32(graph["p_instance"])[None]
+    smask, emask, omask = graph["state_mask"][None], graph["eef_mask"][None], np.asarray(graph["obj_mask"], bool)
+    max_nobj = p_inst.shape[1]
+    errors = []
+    for t, (s, e) in enumerate(schedule):
+        n_rel, recv, send = build_edges(state[:, -1], adj_thresh, smask, emask, topk, connect_tool_all, "single")
+        pred, _ = forward(weights, state, attrs, action, p_inst, _f32(phys)[None], n_rel, recv, send)
+        gt = np.zeros((max_nobj, 3), np.float32)
+        gt[:len(fps_idx)] = obj_pos[e][fps_idx]
+        errors.append(float(np.linalg.norm(pred[0][omask] - gt[omask], axis=-1).mean()))
+        if t + 1 < len(schedule):
+            s2, e2 = schedule[t + 1]
+            cur = np.concatenate([pred[0], eef_pos[s2]], 0)
+            state = np.concatenate([state[:, 1:], cur[None, None]], 1)
+            action = np.zeros_like(action)
+            action[0, max_nobj:] = eef_pos[e2] - eef_pos[s2]
+    return errors

@@ -319,6 +319,132 @@ def gen_sysid(R):
              chamfer_p1=np.asarray(per, np.float64), **out)
 
 
+# ------------------------------------------------------------------ eval rollout over a dataset ("next" row n3)
+def write_eval_dataset(root, g):
+    """Lay a fixture (arrays in an npz / dict) out in the reference's on-disk dataset format under `root`."""
+    import pickle
+    name = str(g["data_name"])
+    n_epi = len(g["n_frames"])
+    prep = os.path.join(root, "preprocess", name)
+    os.makedirs(os.path.join(prep, "frame_pairs"), exist_ok=True)
+    eef, obj = [], []
+    for e in range(n_epi):
+        os.makedirs(os.path.join(root, "sim_data", name, f"{e:06}"), exist_ok=True)
+        with open(os.path.join(root, "sim_data", name, f"{e:06}", "property_params.pkl"), "wb") as f:
+            pickle.dump({"particle_radius": 0.03, "stiffness": float(g["stiffness"][e])}, f)
+        T = int(g["n_frames"][e])
+        eef.append(np.asarray(g["eef_pos"][e, :T]))
+        obj.append(np.asarray(g["obj_pos"][e, :T]))
+        for k in range(int(g["n_push"][e])):
+            np.savetxt(os.path.join(prep, "frame_pairs", f"{e:06}_{k + 1:02}.txt"), g[f"pairs_{e}_{k + 1}"], fmt="%d")
+    with open(os.path.join(prep, "positions.pkl"), "wb") as f:
+        pickle.dump({"eef_pos": eef, "obj_pos": obj}, f)
+
+
+def gen_evalrollout(R):
+    import contextlib
+    import importlib
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "adaptigraph_amd"))
+    from adaptigraph_amd import sampling
+    dgraph = importlib.import_module("dynamics.dataset.graph")
+    # DGL is absent: stage 1 of fps() runs OUR restatement of dgl.geometry.farthest_point_sampler (tensor in, tensor out)
+    dgraph.farthest_point_sampler = lambda x, n, start_idx=0: torch.from_numpy(sampling.farthest_point_sampler(x.numpy(), n, start_idx))
+    rr = importlib.import_module("dynamics.rollout.rollout")
+    rg = importlib.import_module("dynamics.rollout.graph")
+    prep = importlib.import_module("dynamics.preprocess.preprocess")
+    dutils = importlib.import_module("dynamics.utils")
+
+    # fps_rad_idx straight from the reference
+    rng = np.random.default_rng(5)
+    cloud = rng.uniform(0, 2, (150, 3)).astype(np.float32)
+    np.random.seed(11)
+    _, rad_idx = dutils.fps_rad_idx(cloud, 0.45)
+    np.random.seed(12)
+    fps_idx = dgraph.fps(cloud, 60, [0.3, 0.5])
+    save("fps_cloud", cloud=cloud, radius=np.float64(0.45), seed=np.int64(11), rad_idx=rad_idx.astype(np.int64),
+         fps_seed=np.int64(12), fps_max_nobj=np.int64(60), fps_range=np.array([0.3, 0.5]), fps_idx=fps_idx.astype(np.int64))
+
+    # synthetic rope dataset: 3 episodes x 2 pushes, tool sweeping through a 120-particle rope
+    dyn, _ = load_cfg("rope")
+    n_his, n_future = dyn["dataset_config"]["n_his"], dyn["dataset_config"]["n_future"]
+    n_part, T_push = 120, 12
+    fx = dict(data_name=np.array("rope"), n_frames=[], n_push=[], stiffness=[])
+    eef_all, obj_all = [], []
+    for e in range(3):
+        r = np.random.default_rng(100 + e)
+        i = np.arange(n_part)
+        obj0 = np.stack([i * 0.04, np.zeros(n_part), 1.2 * np.sin(2 * np.pi * i / n_part)], 1) + r.normal(0, 0.01, (n_part, 3))
+        eef_e, obj_e, n_frames = [], [], 0
+        cur = obj0.copy()
+        for k in range(2):
+            a = r.uniform(0, 2 * np.pi)
+            p0 = np.array([r.uniform(1.0, 3.8), 0.0, r.uniform(-1.0, 1.0)])
+            step = 0.06 * np.array([np.cos(a), 0.0, np.sin(a)])
+            eef_k, obj_k = [], []
+            for tt_ in range(T_push):
+                tool = p0 + step * tt_
+                d = np.linalg.norm(cur[:, [0, 2]] - tool[[0, 2]], axis=1)
+                cur = cur + np.exp(-(d / 0.3) ** 2)[:, None] * step * 0.8 + r.normal(0, 0.002, cur.shape)
+                eef_k.append(tool[None].copy()); obj_k.append(cur.copy())
+            eef_k, obj_k = np.array(eef_k), np.array(obj_k)
+            with contextlib.redirect_stdout(io.StringIO()):
+                pairs, cnt = prep.extract_push(eef_k, dyn["dataset_config"]["dist_thresh"], n_his, n_future, n_frames)
+            n_frames += cnt
+            fx[f"pairs_{e}_{k + 1}"] = np.asarray(pairs, np.int64)
+            eef_e.append(eef_k); obj_e.append(obj_k)
+        fx["n_frames"].append(n_frames); fx["n_push"].append(2); fx["stiffness"].append(r.uniform(0.1, 0.9))
+        eef_all.append(np.concatenate(eef_e).astype(np.float32)); obj_all.append(np.concatenate(obj_e).astype(np.float32))
+    fx["eef_pos"], fx["obj_pos"] = np.stack(eef_all), np.stack(obj_all)
+    fx = {k: np.asarray(v) for k, v in fx.items()}
+
+    with tempfile.TemporaryDirectory() as root:
+        write_eval_dataset(root, fx)
+        ds = dict(dyn["dataset_config"], data_dir=os.path.join(root, "sim_data"), prep_data_dir=os.path.join(root, "preprocess"),
+                  device="cpu", ratio={"train": [0, 0.34], "valid": [0.34, 1.0]})
+        ds["datasets"] = [dict(ds["datasets"][0], max_nobj=40, max_nR=400)]
+        config = dict(dyn, dataset_config=ds)
+        model = build_model(R, "rope")
+        # pieces, for the loaders / graph set-up tests
+        pair_lists, phys = R_load(ds, dyn["material_config"])
+        eef_pos, obj_pos = importlib.import_module("dynamics.dataset.load").load_positions(ds)
+        np.random.seed(3)
+        pair0 = fx["pairs_1_1"][0]
+        graph, fidx = rg.construct_graph(ds, dyn["material_config"], eef_pos[1], obj_pos[1], n_his, pair0, phys[1])
+        pairs_e1 = pair_lists[pair_lists[:, 0] == 1][:, 1:]
+        sched, cur = [(int(pair0[n_his - 1]), int(pair0[n_his]))], int(pair0[n_his])
+        while True:
+            nxt = rg.get_next_pair_or_break_episode_pushes(pairs_e1, n_his, obj_pos[1].shape[0], cur)
+            if nxt is None:
+                break
+            sched.append((int(nxt[n_his - 1]), int(nxt[n_his]))); cur = int(nxt[n_his])
+        nxt_skip = rg.get_next_pair_or_break_episode(pairs_e1[pairs_e1[:, n_his - 1] % 3 == 0], n_his, obj_pos[1].shape[0], 1)
+        # the whole driver
+        out_dir = os.path.join(root, "out")
+        os.makedirs(out_dir)
+        np.random.seed(42)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rr.rollout_dataset(model, "cpu", config, out_dir, False)
+        errs = {}
+        for e in (1, 2):
+            for k in (1, 2):
+                errs[f"error_{e}_{k}"] = np.loadtxt(os.path.join(out_dir, f"{e}", "short", f"error_{k}.txt"))
+        save("evalrollout_rope", **fx, seed=np.int64(42), max_nobj=np.int64(40), max_nR=np.int64(400),
+             pair_lists=pair_lists.astype(np.int64), phys_norm=np.array([p["rope"] for p in phys], np.float32),
+             graph_seed=np.int64(3), graph_pair=pair0, graph_fps_idx=np.asarray(fidx, np.int64),
+             **{"graph_" + k: v.numpy() for k, v in graph.items()}, schedule=np.array(sched, np.int64),
+             next_skip=np.asarray(nxt_skip, np.int64), error_short=np.loadtxt(os.path.join(out_dir, "error_short.txt")), **errs)
+
+
+def R_load(ds, material_config):
+    import contextlib
+    import importlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return importlib.import_module("dynamics.dataset.load").load_dataset(ds, material_config, phase="valid")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -327,12 +453,15 @@ def main():
         return gen_mppi(R)
     if len(sys.argv) > 1 and sys.argv[1] == "sysid":
         return gen_sysid(R)
+    if len(sys.argv) > 1 and sys.argv[1] == "evalrollout":
+        return gen_evalrollout(R)
     gen_weights(R)
     gen_edges(R)
     gen_forward(R)
     gen_rollout(R)
     gen_mppi(R)
     gen_sysid(R)
+    gen_evalrollout(R)
 
 
 if __name__ == "__main__":
