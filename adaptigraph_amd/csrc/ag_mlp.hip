@@ -23,6 +23,7 @@
 //  * All kernels are persistent (<= 2 workgroups per CU walk the 128-row tiles with a grid stride); the weight
 //    ring keeps turning across row tiles.  256-thread workgroups, one wave per SIMD, 2 workgroups per CU.
 #include "ag_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,6 +35,38 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) — inline-asm immediates need constant expressions
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Weight-fragment reads of the split-bf16 kernels, issued from inline asm with hand-counted waits.  Left to the
+// compiler, the software-pipelined reads of a tile are re-serialised by the machine scheduler in most tiles (one
+// register, `s_waitcnt lgkmcnt(0)` after every ds_read: each k16-step then eats a full LDS round trip).  LDS returns
+// data in order, so `lgkmcnt(n)` with n = number of fragment reads issued AFTER the wanted pair is exact for them;
+// compiler-issued LDS/SMEM traffic in between can only make the wait stricter.  The wait is tied to the fragment
+// registers ("+v") so their MFMAs cannot be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8 &d, unsigned lds_byte_addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lds_byte_addr), "n"(OFF));
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait_pair(bf16x8 &a, bf16x8 &b)
+{
+    static_assert(PENDING >= 0 && PENDING <= 15, "lgkmcnt is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(PENDING));
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
 
 struct ChunkPipe {
     const float4 *g;   // weight stream (global), chunk k at g + k*AG_CHUNK_F4; the stream is walked cyclically
@@ -293,32 +326,36 @@ struct PrecB3 {
         };
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
-            const bf16x8 *buf = reinterpret_cast<const bf16x8 *>(P.lds + P.buf * AG_CHUNK_FLOATS) + lane;
+            const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
             if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
-#pragma unroll
-            for (int u = 0; u < PF && u < NU; ++u) { wq[u][0] = buf[(2 * u) * 64]; wq[u][1] = buf[(2 * u + 1) * 64]; }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PF < NU ? PF : NU), 0);   // prologue reads first
+            static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                lds_read16<(2 * u) * 1024>(wq[u][0], la);
+                lds_read16<(2 * u + 1) * 1024>(wq[u][1], la);
+            });
             if (ti > 0) finish(ti - 1, prev);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                if (u + PF < NU) {
-                    wq[(u + PF) % (PF + 1)][0] = buf[(2 * (u + PF)) * 64];
-                    wq[(u + PF) % (PF + 1)][1] = buf[(2 * (u + PF) + 1) * 64];
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if constexpr (u + PF < NU) {
+                    lds_read16<(2 * (u + PF)) * 1024>(wq[(u + PF) % (PF + 1)][0], la);
+                    lds_read16<(2 * (u + PF) + 1) * 1024>(wq[(u + PF) % (PF + 1)][1], la);
                 }
+                constexpr int ahead = (NU - 1 - u) < PF ? (NU - 1 - u) : PF;     // k16-steps whose reads were issued after step u's
+                lds_wait_pair<2 * ahead>(wq[u % (PF + 1)][0], wq[u % (PF + 1)][1]);
                 const bf16x8 wh = wq[u % (PF + 1)][0], wl = wq[u % (PF + 1)][1];
                 bf16x8 xh = in.hi[u], xl = in.lo[u];
-                if (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3)
+                if constexpr (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3)
                     constexpr int o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
                     if (h == hb) { xh[e] = (__bf16)1.0f; xl[e] = (__bf16)0.0f; }
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
-            }
+            });
             prev = acc;
-            if (ti == 0) pipe_wait<0>(); else pipe_wait<Epi::kStores>();
+            if (!(AG_ABL & 16)) { if (ti == 0) pipe_wait<0>(); else pipe_wait<Epi::kStores>(); }
             if (!(AG_ABL & 2)) __syncthreads();
             P.buf ^= 1;
         }
@@ -333,24 +370,39 @@ struct PrecB3 {
         constexpr int NU = (K + 15) / 16;
         static_assert(NU <= 2, "compact first layer");
         const int lane = threadIdx.x & 63;
-        const bf16x8 *buf = reinterpret_cast<const bf16x8 *>(P.lds + P.buf * AG_CHUNK_FLOATS) + lane;
+        const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
         pipe_dma(P, P.buf ^ 1);
-#pragma unroll
-        for (int ti = 0; ti < AG_NT; ++ti) {
+        // fragments of out-tile ti+1 are read while tile ti's MFMAs run (<= 4*NU reads in flight)
+        bf16x8 wq[2][NU][2];
+        static_for<0, NU>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            lds_read16<(u * 2) * 1024>(wq[0][u][0], la);
+            lds_read16<(u * 2 + 1) * 1024>(wq[0][u][1], la);
+        });
+        static_for<0, AG_NT>([&](auto T) {
+            constexpr int ti = decltype(T)::value;
+            if constexpr (ti + 1 < AG_NT)
+                static_for<0, NU>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    lds_read16<(((ti + 1) * NU + u) * 2) * 1024>(wq[(ti + 1) & 1][u][0], la);
+                    lds_read16<(((ti + 1) * NU + u) * 2 + 1) * 1024>(wq[(ti + 1) & 1][u][1], la);
+                });
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const bf16x8 wh = buf[((ti * NU + u) * 2) * 64], wl = buf[((ti * NU + u) * 2 + 1) * 64];
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                constexpr int later = (NU - 1 - u) + (ti + 1 < AG_NT ? NU : 0);      // pairs issued after this one
+                lds_wait_pair<2 * later>(wq[ti & 1][u][0], wq[ti & 1][u][1]);
+                const bf16x8 wh = wq[ti & 1][u][0], wl = wq[ti & 1][u][1];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, in.hi[u], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in.lo[u], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in.hi[u], acc, 0, 0, 0);
-            }
+            });
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
             sink(ti, acc);
-        }
+        });
         pipe_wait<0>();
         __syncthreads();
         P.buf ^= 1;
