@@ -34,7 +34,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// max(x, 0) as ONE op: fp32 bit patterns order like int32 for x >= 0 and every negative float is a negative int, so
+// relu(x) = as_float(max(as_int(x), 0)) (v_max_i32).  Through fmaxf / fmed3 the compiler adds a canonicalising
+// `v_max_f32 x, x, x` per value.  (Not inline asm: the MFMA -> VALU read hazard is software-managed and the hazard
+// recogniser does not look inside asm.)
+__device__ __forceinline__ float relu1(float x)
+{
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+// two fp32 -> packed bf16, round-to-nearest-even (v_cvt_pk_bf16_f32), low half = a
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) — inline-asm immediates need constant expressions
 template <int I, int N, class F>
@@ -292,17 +308,26 @@ struct PrecB3 {
     // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
     // which is accumulator register 8s + e of out-tile t — so a finished tile converts in place, no shuffles.
     struct Act { bf16x8 hi[2 * AG_NT], lo[2 * AG_NT]; };
+    // hi = bf16(x) (RNE), lo = bf16(x - hi), two values per packed convert: 6 VALU ops per value pair.  (Written on pairs
+    // with explicit converts: from per-element `(__bf16)x` the compiler emitted ~3x as many ops, and the relu+split
+    // epilogues were co-limiting the kernels with the MFMAs.)
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
     {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            u32x4 H, L;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = v[8 * s + e];
-                const __bf16 hb = (__bf16)x;                 // round-to-nearest-even (v_cvt_pk_bf16_f32)
-                a.hi[2 * ti + s][e] = hb;
-                a.lo[2 * ti + s][e] = (AG_ABL & 1) ? hb : (__bf16)(x - (float)hb);
+            for (int w = 0; w < 4; ++w) {
+                const float x0 = v[8 * s + 2 * w], x1 = v[8 * s + 2 * w + 1];
+                const unsigned hp = cvt_pk_bf16(x0, x1);
+                const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
+                H[w] = hp;
+                L[w] = (AG_ABL & 1) ? hp : cvt_pk_bf16(x0 - h0, x1 - h1);
             }
+            a.hi[2 * ti + s] = __builtin_bit_cast(bf16x8, H);
+            a.lo[2 * ti + s] = __builtin_bit_cast(bf16x8, L);
+        }
     }
 
     template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
