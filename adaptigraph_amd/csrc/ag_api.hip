@@ -211,6 +211,7 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
     a.hs_out = c.take<float>(L.rows_pad * AG_FP);
     a.agg = c.take<float>(L.rows_pad * AG_FP);
     a.eterm = c.take<float>(L.e_pad * AG_FP);
+    a.tile_ctr = c.take<int>(AG_TILE_CTRS);
 }
 
 void carve_edges(Carver &c, AgEdgeArgs &a)
@@ -259,6 +260,7 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
     a.precision = m->precision;
     a.eterm_half = m->eterm_half;
     a.max_blocks = m->max_blocks;
+    if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
 }

@@ -66,7 +66,9 @@ struct AgFwdArgs {
     int eterm_half;    // 1: the Eterm table is fp16 in accumulator order (precision mode 2)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
+    int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
 };
+#define AG_TILE_CTRS 4
 
 // kernel launchers (one translation unit each)
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);

@@ -84,12 +84,25 @@ __device__ __forceinline__ unsigned lds_addr_of(const void *p)
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
+#ifndef AG_TRACE
+#define AG_TRACE 0      // debug builds only (tools/trace_tiles.py): s_memtime stamps of one wave's tile phases
+#endif
+#if AG_TRACE
+__device__ unsigned long long ag_trace_buf[4 * 512];
+#define AG_STAMP(P) do { if ((P).tr >= 0 && (P).tr < 512) { ag_trace_buf[(P).trb + (P).tr] = __builtin_readcyclecounter(); (P).tr++; } } while (0)
+#else
+#define AG_STAMP(P) do { } while (0)
+#endif
+
 struct ChunkPipe {
     const float4 *g;   // weight stream (global), chunk k at g + k*AG_CHUNK_F4; the stream is walked cyclically
     int total;         // chunks in the stream (= chunks per row tile)
     int fetch;         // next stream chunk to fetch (wraps at total)
     int buf;           // LDS buffer holding the current chunk (0/1)
     float *lds;        // 2 * AG_CHUNK_FLOATS
+#if AG_TRACE
+    int tr = -1, trb = 0;
+#endif
 };
 
 // Asynchronous global -> LDS copy of the next weight chunk (global_load_lds_dwordx4: LDS-DMA, no VGPR staging,
@@ -352,7 +365,9 @@ struct PrecB3 {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+            AG_STAMP(P);
             if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
+            AG_STAMP(P);
             f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
             static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
@@ -361,6 +376,7 @@ struct PrecB3 {
                 lds_read16<(2 * u + 1) * 1024>(wq[u][1], la);
             });
             if (ti > 0) finish(ti - 1, prev);
+            AG_STAMP(P);
             static_for<0, NU>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 if constexpr (u + PF < NU) {
@@ -380,8 +396,11 @@ struct PrecB3 {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
             });
             prev = acc;
+            AG_STAMP(P);
             if (!(AG_ABL & 16)) { if (ti == 0) pipe_wait<0>(); else pipe_wait<Epi::kStores>(); }
+            AG_STAMP(P);
             if (!(AG_ABL & 2)) __syncthreads();
+            AG_STAMP(P);
             P.buf ^= 1;
         }
         finish(NT - 1, prev);
@@ -533,7 +552,21 @@ __device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool v
     }
 }
 
-#define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS];
+#define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS]; __shared__ int s_next_tile[2];
+
+// Row tiles are CLAIMED from a per-launch counter instead of walked with a static grid stride: the two workgroups that
+// share a CU do not progress at the same rate (issue arbitration is oldest-first, so the workgroup launched second runs
+// ~40 % slower per row tile, s_memtime trace), and with a static split the early finishers leave their CU half empty for
+// the tail.  The atomic is issued together with the row tile's first loads (whose wait it shares) and the claimed index
+// travels through LDS under the tile's own barriers, so the queue costs no extra round trip or barrier.
+struct TileQueue {
+    int *ctr, *slot;
+    int tile, par, claimed;
+    __device__ __forceinline__ TileQueue(int *c, int *s) : ctr(c), slot(s), tile(blockIdx.x), par(0), claimed(0) {}
+    __device__ __forceinline__ void claim() { if (threadIdx.x == 0) claimed = ctr ? (int)gridDim.x + atomicAdd(ctr, 1) : tile + (int)gridDim.x; }
+    __device__ __forceinline__ void publish() { if (threadIdx.x == 0) slot[par] = claimed; }   // >= 1 barrier before next()
+    __device__ __forceinline__ void next() { tile = slot[par]; par ^= 1; }                      // after the row tile's last barrier
+};
 
 template <class Prec> __device__ __forceinline__ const float4 *pick(const float4 *f32, const float4 *b3);
 template <> __device__ __forceinline__ const float4 *pick<PrecF32>(const float4 *f32, const float4 *) { return f32; }
@@ -556,8 +589,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     ChunkPipe P{pick<Prec>(w.node_encode, w.node_encode_b3), 26, 0, 0, lds};
     pipe_start(P);
+    TileQueue q(nullptr, s_next_tile);   // ~4 row tiles per workgroup: nothing to balance, static stride
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    while (q.tile < ntiles) {
+        const int tile = q.tile;
+        q.claim();
         const int g = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = g < Mn;
         const int gc = valid ? g : 0;
@@ -585,11 +621,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
         const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         dense_first<Prec, AG_NODE_IN_MAX>(P, x, y);
+        q.publish();
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
         dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
         dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff});  // Hr
         dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff});  // Hs
+        q.next();
     }
 }
 
@@ -612,8 +650,21 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
     if ((int)blockIdx.x >= ntiles) return;
     ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 16, 0, 0, lds};
     pipe_start(P);
+    TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
+    int it = -1;
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    while (q.tile < ntiles) {
+        const int tile = q.tile;
+        q.claim();
+        ++it;
+#if AG_TRACE
+        {   // record the 6th row tile of wave 0 in blocks 0, 1, 256, 257
+            const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 256 ? 2 : blockIdx.x == 257 ? 3 : -1;
+            P.tr = (it == 5 && slot >= 0 && wave == 0) ? 0 : -1;
+            P.trb = (slot < 0 ? 0 : slot) * 512;
+            AG_STAMP(P);
+        }
+#endif
         const int e = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = e < E;
         const int r = (AG_ABL & 64) ? (e & 1023) : (valid ? a.edge_recv[e] : 0), s = (AG_ABL & 64) ? ((e * 7) & 1023) : (valid ? a.edge_send[e] : 0);
@@ -662,12 +713,14 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
         dense_first<Prec, AG_EDGE_IN + 1>(P, x, y);
+        q.publish();
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
         if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
             dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h});
         else
             dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)e * AG_FP + 4 * h});
+        q.next();
     }
 }
 
@@ -685,8 +738,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     ChunkPipe P{LAST ? pick<Prec>(w.node_last, w.node_last_b3) : pick<Prec>(w.node_mid, w.node_mid_b3), LAST ? 16 : 15, 0, 0, lds};
     pipe_start(P);
+    TileQueue q(nullptr, s_next_tile);   // ~4 row tiles per workgroup: nothing to balance, static stride
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    while (q.tile < ntiles) {
+        const int tile = q.tile;
+        q.claim();
         const int g = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = g < Mn;
         const int gc = valid ? g : 0;
@@ -703,12 +759,14 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         if (!LAST) {
             dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
+            q.publish();
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff});
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff});
         } else {
             dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
+            q.publish();
             dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
             dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
             f32x16 m;
@@ -727,10 +785,18 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
                 }
             }
         }
+        q.next();
     }
 }
 
 }  // namespace
+
+#if AG_TRACE
+extern "C" int ag_debug_trace_read(unsigned long long *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ag_trace_buf), sizeof(unsigned long long) * 4 * 512);
+}
+#endif
 
 static inline int grid_for(int rows, int max_blocks)
 {
