@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 // Same reduction with Eterm stored as fp16 in accumulator order (precision mode 2: half the dominant HBM stream).
 // A row is 160 halves = 20 x 16 B; thread c of a node owns half-positions [8c, 8c+8) = features
 // f0 = 32t + 8q0 + 4h + {0..3} and f0 + 8 (t = c/4, h = (c%4)/2, q0 = 2*(c%2)).
+// A node has ~10 edges and every edge costs a dependent index -> row round trip, so FOUR edges are kept in flight per
+// lane and the sender indices of the next four are fetched one iteration ahead (the adds still run in ascending edge
+// order: bit-identical to a sequential loop).  Measured 0.303 -> 0.292 ms vs two in flight; nontemporal Eterm loads: worse.
 constexpr int kNodesPerBlockH = 12;   // 12 nodes x 20 lanes = 240 of 256 lanes busy
+constexpr int kInFlight = 4;
 
 __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 {
@@ -74,37 +78,37 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     const int f0 = 32 * (c >> 2) + 8 * (2 * (c & 1)) + 4 * ((c >> 1) & 1);
     const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const _Float16 *et = reinterpret_cast<const _Float16 *>(a.eterm) + 8 * c;
+    const float *hs = a.hs + f0;
+    int s[kInFlight];
+#pragma unroll
+    for (int i = 0; i < kInFlight; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
     const float4 hr0 = *reinterpret_cast<const float4 *>(a.hr + (size_t)g * AG_FP + f0);
     const float4 hr1 = *reinterpret_cast<const float4 *>(a.hr + (size_t)g * AG_FP + f0 + 8);
-    const _Float16 *et = reinterpret_cast<const _Float16 *>(a.eterm) + 8 * c;
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    int e = e0;
-    for (; e + 1 < e1; e += 2) {   // two edges in flight per lane
-        const int s0 = a.edge_send[e], s1 = a.edge_send[e + 1];
-        const h8 t0 = *reinterpret_cast<const h8 *>(et + (size_t)e * AG_FP);
-        const h8 t1 = *reinterpret_cast<const h8 *>(et + (size_t)(e + 1) * AG_FP);
-        const float4 u00 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + f0);
-        const float4 u01 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + f0 + 8);
-        const float4 u10 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s1 * AG_FP + f0);
-        const float4 u11 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s1 * AG_FP + f0 + 8);
-        acc0.x += fmaxf(((float)t0[0] + hr0.x) + u00.x, 0.f); acc0.y += fmaxf(((float)t0[1] + hr0.y) + u00.y, 0.f);
-        acc0.z += fmaxf(((float)t0[2] + hr0.z) + u00.z, 0.f); acc0.w += fmaxf(((float)t0[3] + hr0.w) + u00.w, 0.f);
-        acc1.x += fmaxf(((float)t0[4] + hr1.x) + u01.x, 0.f); acc1.y += fmaxf(((float)t0[5] + hr1.y) + u01.y, 0.f);
-        acc1.z += fmaxf(((float)t0[6] + hr1.z) + u01.z, 0.f); acc1.w += fmaxf(((float)t0[7] + hr1.w) + u01.w, 0.f);
-        acc0.x += fmaxf(((float)t1[0] + hr0.x) + u10.x, 0.f); acc0.y += fmaxf(((float)t1[1] + hr0.y) + u10.y, 0.f);
-        acc0.z += fmaxf(((float)t1[2] + hr0.z) + u10.z, 0.f); acc0.w += fmaxf(((float)t1[3] + hr0.w) + u10.w, 0.f);
-        acc1.x += fmaxf(((float)t1[4] + hr1.x) + u11.x, 0.f); acc1.y += fmaxf(((float)t1[5] + hr1.y) + u11.y, 0.f);
-        acc1.z += fmaxf(((float)t1[6] + hr1.z) + u11.z, 0.f); acc1.w += fmaxf(((float)t1[7] + hr1.w) + u11.w, 0.f);
-    }
-    if (e < e1) {
-        const int s0 = a.edge_send[e];
-        const h8 t0 = *reinterpret_cast<const h8 *>(et + (size_t)e * AG_FP);
-        const float4 u00 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + f0);
-        const float4 u01 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + f0 + 8);
-        acc0.x += fmaxf(((float)t0[0] + hr0.x) + u00.x, 0.f); acc0.y += fmaxf(((float)t0[1] + hr0.y) + u00.y, 0.f);
-        acc0.z += fmaxf(((float)t0[2] + hr0.z) + u00.z, 0.f); acc0.w += fmaxf(((float)t0[3] + hr0.w) + u00.w, 0.f);
-        acc1.x += fmaxf(((float)t0[4] + hr1.x) + u01.x, 0.f); acc1.y += fmaxf(((float)t0[5] + hr1.y) + u01.y, 0.f);
-        acc1.z += fmaxf(((float)t0[6] + hr1.z) + u01.z, 0.f); acc1.w += fmaxf(((float)t0[7] + hr1.w) + u01.w, 0.f);
+    for (int e = e0; e < e1; e += kInFlight) {
+        int sn[kInFlight];
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i) sn[i] = e + kInFlight + i < e1 ? a.edge_send[e + kInFlight + i] : -1;
+        h8 t[kInFlight];
+        float4 u0[kInFlight], u1[kInFlight];
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i)
+            if (s[i] >= 0) {
+                t[i] = *reinterpret_cast<const h8 *>(et + (size_t)(e + i) * AG_FP);
+                u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
+                u1[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP + 8);
+            }
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i)
+            if (s[i] >= 0) {
+                acc0.x += fmaxf(((float)t[i][0] + hr0.x) + u0[i].x, 0.f); acc0.y += fmaxf(((float)t[i][1] + hr0.y) + u0[i].y, 0.f);
+                acc0.z += fmaxf(((float)t[i][2] + hr0.z) + u0[i].z, 0.f); acc0.w += fmaxf(((float)t[i][3] + hr0.w) + u0[i].w, 0.f);
+                acc1.x += fmaxf(((float)t[i][4] + hr1.x) + u1[i].x, 0.f); acc1.y += fmaxf(((float)t[i][5] + hr1.y) + u1[i].y, 0.f);
+                acc1.z += fmaxf(((float)t[i][6] + hr1.z) + u1[i].z, 0.f); acc1.w += fmaxf(((float)t[i][7] + hr1.w) + u1[i].w, 0.f);
+            }
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i) s[i] = sn[i];
     }
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0) = acc0;
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
