@@ -409,7 +409,59 @@ __global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
 }
 
 // connect_tools_all overrides: merge {kept object senders} with {all tool senders} in ascending order.
+//   single (graph.py:77-80): tool receivers end with no edges; batch (:134-144): gated by batch_mask, and tool receivers
+//   keep tool->tool edges (incl. the self loop) when it is set.
+// One THREAD per receiver: the kept senders are already ascending and at most top-k long, the sample's tool indices are
+// compacted once per workgroup into LDS (ascending), so a row is a two-pointer merge of two short sorted lists.
+// (A wave per receiver sweeping all N candidate senders was 45 % of the whole cloth-4k step.)
+constexpr int kToolListMax = 8192;     // LDS-resident tool list; more tools than this take the sweep kernel below
+
 __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
+{
+    extern __shared__ int tools[];
+    __shared__ int wcount[4];
+    const int b = blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    int nt = 0;
+    for (int j0 = 0; j0 < N; j0 += 256) {          // ordered compaction of the sample's tool indices
+        const int j = j0 + tid;
+        const bool t = j < N && tl[j];
+        const unsigned long long bal = __ballot(t);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int base = nt;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (t && slot < a.cap) tools[slot] = j;      // only the first `cap` tools can reach a (cap-long) output row
+        nt += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= N) return;
+    const size_t row = (size_t)b * N + i;
+    const bool mi = mk[i], ti = tl[i];
+    const int deg0 = a.deg[row];
+    const bool add_tools = mi && (a.variant == 1 ? (a.flag[b] != 0) : !ti);
+    const bool keep_sel = !ti;
+    const int32_t *in = a.sel0 + row * a.cap0;
+    int32_t *dst = a.sel + row * a.cap;
+    const int na = keep_sel ? deg0 : 0, nb = add_tools ? (nt < a.cap ? nt : a.cap) : 0;
+    int ia = 0, ib = 0, out = 0;
+    int sa = -1;
+    while (ia < na) { sa = in[ia]; if (!tl[sa]) break; ++ia; }          // tool senders among the kept ones come from list B
+    while (ia < na || ib < nb) {
+        const bool take_a = ia < na && (ib >= nb || sa < tools[ib]);
+        const int j = take_a ? sa : tools[ib];
+        if (out < a.cap) dst[out] = j;
+        ++out;
+        if (take_a) { ++ia; while (ia < na) { sa = in[ia]; if (!tl[sa]) break; ++ia; } }
+        else ++ib;
+    }
+    a.deg[row] = out < a.cap ? out : a.cap;
+}
+
+// same result for samples with more than kToolListMax tools: one wave per receiver sweeps every candidate sender
+__global__ __launch_bounds__(256) void finalize_connect_sweep_kernel(AgEdgeArgs a)
 {
     const int b = blockIdx.y, N = a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -420,8 +472,6 @@ __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
     const bool mi = mk[i], ti = tl[i];
     const int deg0 = a.deg[row];
     const int mysel = lane < deg0 ? a.sel0[row * a.cap0 + lane] : -1;
-    // single (graph.py:77-80): tool receivers end with no edges; batch (:134-144): gated by batch_mask,
-    // and tool receivers keep tool->tool edges (incl. the self loop) when it is set
     const bool add_tools = mi && (a.variant == 1 ? (a.flag[b] != 0) : !ti);
     const bool keep_sel = !ti;
     int out = 0;
@@ -532,7 +582,10 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     const int32_t *sel = a.sel0;
     int cap = a.cap0;
     if (a.connect) {
-        hipLaunchKernelGGL(finalize_connect_kernel, dim3((a.N + 3) / 4, a.B), dim3(256), 0, s, a);
+        if (a.cap <= kToolListMax)             // cap = top-k + the caller's bound on tools per sample
+            hipLaunchKernelGGL(finalize_connect_kernel, dim3((a.N + 255) / 256, a.B), dim3(256), (size_t)a.cap * sizeof(int), s, a);
+        else
+            hipLaunchKernelGGL(finalize_connect_sweep_kernel, dim3((a.N + 3) / 4, a.B), dim3(256), 0, s, a);
         sel = a.sel;
         cap = a.cap;
     }
