@@ -38,6 +38,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM_GBS = 8000.0                # HBM3E spec; 6290 GB/s is the measured float4-copy ceiling (same file)
 FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # edge encoder 17->150->150->150 + W_rp[:, :150] block
 PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
+# measured HBM traffic per launch, bytes (KB counters x 1024): edge_encode 2 x 27 176 KB read + 782 653 KB written;
+# aggregate_half 2 x 555 526 KB read + 160 160 KB written
+PMC_TRAFFIC = {("rope", 256, "fast", "edge_encode"): (2 * 27175.8 + 782652.8) * 1024,
+               ("rope", 256, "fast", "aggregate"): (2 * 555526.0 + 160160.4) * 1024}
 DTYPE = {"f32": "f32 (exact fp32 MFMA)",
          "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
          "fast": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate; per-edge table stored f16"}
@@ -167,8 +171,13 @@ def main():
             flop_edge = FLOP_PER_EDGE * (3 if b3 else 1)
             peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
             achieved = flop_edge * e_per / avg_s / 1e12
+            # HBM bytes per launch from the PMC passes committed in profiles/r01_final_traffic_1stream.txt (FETCH_SIZE x 2
+            # per the gfx950 correction + WRITE_SIZE); only known for the default workload, null otherwise
+            traffic = PMC_TRAFFIC.get((args.material, args.batch, args.precision, "edge_encode"))
             roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final_traffic_1stream.txt)",
+                    "algorithmic_bytes": e_per * ((320 if args.precision == "fast" else 640) + 68),
                     "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": flop_edge,
                     "fp32_equivalent_tflops": FLOP_PER_EDGE * e_per / avg_s / 1e12,
                     "mfma": "v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi)" if b3 else "v_mfma_f32_32x32x2_f32",
@@ -181,7 +190,8 @@ def main():
                 nbytes = e_per * (320 if args.precision == "fast" else 640) + n_nodes * 3 * 640
                 a_s = ms[ka] / cnt[ka] * 1e-3
                 roof_hbm = {"bound": "hbm", "kernel": "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS,
+                            "traffic": PMC_TRAFFIC.get((args.material, args.batch, args.precision, "aggregate")),
                             "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
