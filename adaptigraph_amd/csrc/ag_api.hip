@@ -373,6 +373,45 @@ int ag_chamfer_masked(const float *x, const uint8_t *x_mask, const float *y, con
     return chamfer_common("ag_chamfer_masked", x, x_mask, y, y_mask, B, N, M, y_batched, out, stream);
 }
 
+int ag_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n_out, int D, ag_stream_t stream)
+{
+    if (n_out < 0 || D < 1) return fail(AG_ERR_ARG, "ag_gather_rows: bad sizes n_out=%lld D=%d", (long long)n_out, D);
+    if (n_out > 0 && (!x || !idx || !out)) return fail(AG_ERR_ARG, "ag_gather_rows: null argument");
+    ag_launch_gather_rows(x, idx, out, n_out, D, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_segment_sum(const float *vals, const int32_t *ptr, const int32_t *perm, float *out, int64_t n_seg, int D, ag_stream_t stream)
+{
+    if (n_seg < 0 || D < 1) return fail(AG_ERR_ARG, "ag_segment_sum: bad sizes n_seg=%lld D=%d", (long long)n_seg, D);
+    if (n_seg > 0 && (!vals || !ptr || !out)) return fail(AG_ERR_ARG, "ag_segment_sum: null argument");
+    ag_launch_segment_sum(vals, ptr, perm, out, n_seg, D, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_message_forward(const float *eterm, const float *hr, const float *hs, const int32_t *row_ptr, const int32_t *send, float *agg,
+                       int64_t n_nodes, int D, ag_stream_t stream)
+{
+    if (n_nodes < 0 || D < 1) return fail(AG_ERR_ARG, "ag_message_forward: bad sizes");
+    if (n_nodes > 0 && (!eterm || !hr || !hs || !row_ptr || !send || !agg)) return fail(AG_ERR_ARG, "ag_message_forward: null argument");
+    ag_launch_message_fwd(eterm, hr, hs, row_ptr, send, agg, n_nodes, D, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_message_backward(const float *eterm, const float *hr, const float *hs, const int32_t *row_ptr, const int32_t *send,
+                        const float *grad_agg, float *grad_edge, float *grad_hr, int64_t n_nodes, int D, ag_stream_t stream)
+{
+    if (n_nodes < 0 || D < 1) return fail(AG_ERR_ARG, "ag_message_backward: bad sizes");
+    if (n_nodes > 0 && (!eterm || !hr || !hs || !row_ptr || !send || !grad_agg || !grad_edge || !grad_hr))
+        return fail(AG_ERR_ARG, "ag_message_backward: null argument");
+    ag_launch_message_bwd(eterm, hr, hs, row_ptr, send, grad_agg, grad_edge, grad_hr, n_nodes, D, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_set_option(ag_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");

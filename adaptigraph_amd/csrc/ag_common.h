@@ -109,5 +109,11 @@ struct AgStepArgs {
     float raise;              // gripper raise (0 when disabled)
 };
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s);
+void ag_launch_gather_rows(const float *x, const int *idx, float *out, long long E, int D, hipStream_t s);
+void ag_launch_segment_sum(const float *vals, const int *ptr, const int *perm, float *out, long long N, int D, hipStream_t s);
+void ag_launch_message_fwd(const float *eterm, const float *hr, const float *hs, const int *row_ptr, const int *send, float *agg,
+                           long long N, int D, hipStream_t s);
+void ag_launch_message_bwd(const float *eterm, const float *hr, const float *hs, const int *row_ptr, const int *send,
+                           const float *g_agg, float *g_e, float *g_hr, long long N, int D, hipStream_t s);
 int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
                       int y_batched, float *out, hipStream_t s);

@@ -90,6 +90,11 @@ def threshold_sq(adj_thresh, B, device, variant):
         if t.numel() == 1:
             t = t.repeat(B)
         return (t * t).contiguous()
+    if isinstance(adj_thresh, (list, tuple, np.ndarray)):     # one host double per sample (e.g. radii drawn by a dataset)
+        r = np.asarray(adj_thresh, np.float64).reshape(-1)
+        assert r.size == B, f"{r.size} radii for {B} samples"
+        v = (r * r).astype(np.float32) if variant == _lib.AG_VARIANT_SINGLE else r.astype(np.float32) * r.astype(np.float32)
+        return torch.from_numpy(np.ascontiguousarray(v)).to(device)
     r = float(adj_thresh)
     if variant == _lib.AG_VARIANT_SINGLE:
         v = np.float32(r * r)

@@ -126,6 +126,25 @@ int ag_chamfer(const float *x, const float *y, int B, int N, int M, int y_batche
 int ag_chamfer_masked(const float *x, const uint8_t *x_mask, const float *y, const uint8_t *y_mask, int B, int N, int M,
                       int y_batched, float *out, ag_stream_t stream);
 
+/* ---- training path: graph pieces of DynamicsPredictor.forward and their adjoints on the CSR adjacency.
+ * Plain row-major fp32 tensors of arbitrary feature width D; every reduction runs in a fixed order (no atomics).
+ *
+ * ag_gather_rows:  out[e,:] = x[idx[e],:]                    — replaces Rr.bmm(X) / Rs.bmm(X), model.py:224-249,283-284
+ * ag_segment_sum:  out[n,:] = sum_{k in [ptr[n],ptr[n+1])} vals[perm ? perm[k] : k, :]
+ *                  — replaces Rr_t.bmm (model.py:295) with perm = NULL over the receiver-sorted edges, and is the adjoint of
+ *                  a gather by any index given that index's (pointer, permutation) view (receivers: row_ptr/NULL;
+ *                  senders: col_ptr/stable argsort of send)
+ * ag_message_forward:  agg[n,:] = sum_{e in row n} relu((eterm[e,:] + hr[n,:]) + hs[send[e],:])
+ *                  — relation_propagator + Rr_t.bmm of one round (model.py:283-295) after the W_rp column split
+ * ag_message_backward: grad_edge[e,:] = grad_agg[recv(e),:] * [pre-activation > 0]  (= d loss / d eterm[e]),
+ *                  grad_hr[n,:] = sum_{e in row n} grad_edge[e,:];  d loss / d hs = ag_segment_sum(grad_edge, col_ptr, perm) */
+int ag_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n_out, int D, ag_stream_t stream);
+int ag_segment_sum(const float *vals, const int32_t *ptr, const int32_t *perm, float *out, int64_t n_seg, int D, ag_stream_t stream);
+int ag_message_forward(const float *eterm, const float *hr, const float *hs, const int32_t *row_ptr, const int32_t *send, float *agg,
+                       int64_t n_nodes, int D, ag_stream_t stream);
+int ag_message_backward(const float *eterm, const float *hr, const float *hs, const int32_t *row_ptr, const int32_t *send,
+                        const float *grad_agg, float *grad_edge, float *grad_hr, int64_t n_nodes, int D, ag_stream_t stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
  * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
  * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the

@@ -360,3 +360,23 @@ def eval_rollout(weights, graph, fps_idx, schedule, eef_pos, obj_pos, adj_thresh
             action = np.zeros_like(action)
             action[0, max_nobj:] = eef_pos[e2] - eef_pos[s2]
     return errors
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Training objective: the n_future unroll of src/dynamics/train/train.py:84-108, forward only,
+# pinned to tests/golden/train_rope.npz (the gradients there come from the reference's autograd).
+# ---------------------------------------------------------------------------------------------------------------
+def unrolled_loss(weights, batch, n_rel, recv, send, n_future=3):
+    state, action = _f32(batch["state"]).copy(), _f32(batch["action"]).copy()
+    n_p = batch["p_instance"].shape[1]
+    loss, preds = 0.0, []
+    for fi in range(n_future):
+        pred, _ = forward(weights, state, batch["attrs"], action, batch["p_instance"], batch["rope_physics_param"], n_rel, recv, send)
+        preds.append(pred)
+        loss += float(np.mean((pred - batch["state_future"][:, fi]) ** 2, dtype=np.float64))
+        if fi < n_future - 1:
+            nxt = _f32(batch["eef_future"][:, fi]).copy()
+            nxt[:, :n_p] = pred
+            state = np.concatenate([state[:, 1:], nxt[:, None]], 1)
+            action = _f32(batch["action_future"][:, fi])
+    return loss, np.stack(preds)

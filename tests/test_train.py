@@ -1,0 +1,192 @@
+"""Training path ("next" row n4): dataset samples, differentiable graph ops, the n_future unroll and its gradients, the
+training loop — against fixtures generated from the reference (tests/golden/train_rope.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from adaptigraph_amd import configs
+from oracle import ag_oracle as ago
+from test_eval_rollout import make_config, write_dataset
+
+KEYS = ["state", "action", "eef_future", "action_future", "state_future", "attrs", "p_instance", "obj_mask", "rope_physics_param"]
+
+
+def train_config(root, g_eval, device="cpu"):
+    cfg = make_config(root, g_eval, device)
+    ds = cfg["dataset_config"]
+    ds.update(ratio={"train": [0, 0.67], "valid": [0.67, 1.0]}, verbose=False,
+              randomness={"use": True, "state_noise": {"train": 0.05, "valid": 0.0}, "phys_noise": {"train": 0.0, "valid": 0.0}})
+    cfg["train_config"].update(phases=["train", "valid"], num_workers=0, batch_size=4, n_epochs=2, log_interval=1,
+                               n_iters_per_epoch={"train": 3, "valid": 2})
+    return cfg
+
+
+@pytest.fixture()
+def dataset_dir(tmp_path):
+    g_eval = load_golden("evalrollout_rope")
+    write_dataset(str(tmp_path), g_eval)
+    return g_eval, str(tmp_path)
+
+
+def batch_from(g):
+    return {k: g["b_" + k] for k in KEYS}
+
+
+def test_dataset_samples_match_reference(dataset_dir):
+    from adaptigraph_amd.dataset import DynDataset
+    g_eval, root = dataset_dir
+    g = load_golden("train_rope")
+    cfg = train_config(root, g_eval)
+    dset = DynDataset(cfg["dataset_config"], cfg["material_config"], phase="train")
+    assert len(dset) == int(g["n_samples"])
+    for k, i in enumerate(g["idx"]):
+        np.random.seed(int(g["seed"]) + k)
+        s = dset[int(i)]
+        for key in KEYS:
+            assert np.array_equal(s[key].numpy(), g["b_" + key][k]), (key, k)
+        assert s["state_mask"].sum() == s["obj_mask"].sum() + 1 and s["eef_mask"].sum() == 1
+        assert 0.48 <= float(s["adj_thresh"]) <= 0.52
+    valid = DynDataset(cfg["dataset_config"], cfg["material_config"], phase="valid")
+    assert len(valid) == 72 - len(dset)
+
+
+def test_oracle_unrolled_loss_matches_reference(weights):
+    g = load_golden("train_rope")
+    loss, preds = ago.unrolled_loss(weights, batch_from(g), g["n_rel"], g["recv"], g["send"])
+    assert abs(loss - float(g["loss"])) <= 1e-6 and np.abs(preds - g["preds"]).max() <= 2e-5
+
+
+def test_train_ops_refuse_cpu():
+    from adaptigraph_amd import train_ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        train_ops._GatherRows.apply(torch.zeros(3, 4), torch.zeros(2, dtype=torch.int32), torch.zeros(4, dtype=torch.int32), None)
+
+
+# ------------------------------------------------------------------------------------------------------ GPU
+DEV = "cuda:0"
+
+
+def tg(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def golden_csr(g, N):
+    from test_gpu_parity import csr_from_lists
+    return csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
+
+
+def trainable(weights):
+    from adaptigraph_amd.train_model import TrainableDynamicsPredictor
+    m = TrainableDynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    return m.to(DEV)
+
+
+@pytest.mark.gpu
+def test_graph_ops_forward_and_adjoint_vs_torch():
+    """gather / message_sum and their hand-written backward kernels against plain torch indexing + autograd (fp64 reference)."""
+    from adaptigraph_amd import graph as aggraph, train_ops
+    rng = np.random.default_rng(0)
+    B, N, D = 3, 37, 150
+    pos = rng.uniform(0, 2.0, (B, N, 3)).astype(np.float32)
+    mask = np.ones((B, N), bool); mask[1, 30:] = False
+    tool = np.zeros((B, N), bool); tool[:, -1] = True
+    csr = aggraph.build_edges(tg(pos), 0.6, tg(mask), tg(tool), 6, False, "batch", max_tools=1)
+    v = train_ops.EdgeViews(csr)
+    assert v.E > 50 and int(v.col_ptr[-1]) == v.E
+    recv, send = v.recv.long(), v.send.long()
+    M = B * N
+    x = torch.randn(M, D, device=DEV, requires_grad=True)
+    e = torch.randn(v.E, D, device=DEV, requires_grad=True)
+    hr = torch.randn(M, D, device=DEV, requires_grad=True)
+    w1, w2 = torch.randn(v.E, D, device=DEV), torch.randn(M, D, device=DEV)
+    out = (train_ops.gather_receivers(x, v) * w1).sum() + (train_ops.gather_senders(x, v) * w1.flip(0)).sum() \
+        + (train_ops.message_sum(e, hr, x, v) * w2).sum()
+    gx, ge, ghr = torch.autograd.grad(out, (x, e, hr))
+    xd, ed, hrd = (t.detach().double().requires_grad_() for t in (x, e, hr))
+    msg = torch.relu(ed + hrd[recv] + xd[send])
+    ref = (xd[recv] * w1.double()).sum() + (xd[send] * w1.flip(0).double()).sum() \
+        + (torch.zeros(M, D, dtype=torch.float64, device=DEV).index_add(0, recv, msg) * w2.double()).sum()
+    rx, re, rhr = torch.autograd.grad(ref, (xd, ed, hrd))
+    assert abs(out.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    for a, b in ((gx, rx), (ge, re), (ghr, rhr)):
+        assert (a.double() - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    g2 = torch.autograd.grad((train_ops.message_sum(e, hr, x, v) * w2).sum(), (x, e, hr))      # fixed-order reductions: bitwise repeatable
+    g3 = torch.autograd.grad((train_ops.message_sum(e, hr, x, v) * w2).sum(), (x, e, hr))
+    assert all(torch.equal(a, b) for a, b in zip(g2, g3))
+
+
+@pytest.mark.gpu
+def test_unrolled_loss_and_gradients_match_reference(weights):
+    from adaptigraph_amd.train_model import unrolled_loss
+    g = load_golden("train_rope")
+    model = trainable(weights).train()
+    data = {k: tg(v) for k, v in batch_from(g).items()}
+    data.update(Rr=golden_csr(g, g["b_attrs"].shape[1]), Rs=None)
+    before = {k: v.clone() for k, v in data.items() if torch.is_tensor(v)}
+    loss = unrolled_loss(model, data, 3)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6 * max(1.0, float(g["loss"]))
+    assert all(torch.equal(data[k], v) for k, v in before.items())          # the batch dict is left untouched
+    loss.backward()
+    for name, p in model.named_parameters():
+        ref = g["grad_" + name]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, name
+    torch.optim.Adam(model.parameters(), lr=0.001).step()
+    key = "particle_encoder.model.0.weight"
+    assert np.abs(model.state_dict()[key].cpu().numpy() - g["adam_" + key]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_trainable_forward_equals_fused_engine(weights):
+    """Same weights, same graph: the autograd forward and the fused inference engine (exact-fp32 mode) agree."""
+    from adaptigraph_amd.model import DynamicsPredictor
+    g = load_golden("train_rope")
+    data = {k: tg(v) for k, v in batch_from(g).items()}
+    csr = golden_csr(g, g["b_attrs"].shape[1])
+    args = (data["state"], data["attrs"], csr, None, data["p_instance"])
+    kw = dict(action=data["action"], rope_physics_param=data["rope_physics_param"])
+    with torch.no_grad():
+        pos_t, mot_t = trainable(weights).eval()(*args, **kw)
+    eng = DynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), DEV)
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    pos_e, mot_e = eng.to(DEV).eval().set_option("precision", 0)(*args, **kw)
+    assert (mot_t - mot_e).abs().max().item() <= 2e-5 and (pos_t - pos_e).abs().max().item() <= 2e-5
+    assert np.abs(pos_t.cpu().numpy() - g["preds"][0]).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_attach_edges_matches_reference_edges(dataset_dir):
+    from adaptigraph_amd.dataset import DynDataset, attach_edges
+    g_eval, root = dataset_dir
+    g = load_golden("train_rope")
+    cfg = train_config(root, g_eval, DEV)
+    dset = DynDataset(cfg["dataset_config"], cfg["material_config"], phase="train")
+    samples = []
+    for k, i in enumerate(g["idx"]):
+        np.random.seed(int(g["seed"]) + k)
+        samples.append(dset[int(i)])
+    data = attach_edges(torch.utils.data.default_collate(samples), cfg["dataset_config"], DEV)
+    assert data["Rr"].n_rel().cpu().tolist() == g["n_rel"].tolist()
+    for b, (r, s) in enumerate(data["Rr"].to_lists()):
+        assert np.array_equal(r, g["recv"][b, :g["n_rel"][b]]) and np.array_equal(s, g["send"][b, :g["n_rel"][b]])
+
+
+@pytest.mark.gpu
+def test_training_loop_learns_and_checkpoints_load_into_engine(dataset_dir):
+    from adaptigraph_amd import train as agtrain
+    from adaptigraph_amd.model import DynamicsPredictor
+    g_eval, root = dataset_dir
+    cfg = train_config(root, g_eval, DEV)
+    cfg["train_config"].update(n_epochs=10, n_iters_per_epoch={"train": 6, "valid": 2}, batch_size=8, random_seed=1)
+    hist = agtrain.train(cfg)
+    assert len(hist["train"]) == 10 and len(hist["valid"]) == 10 and np.isfinite(hist["train"]).all()
+    assert np.mean(hist["train"][-3:]) < 0.7 * hist["train"][0]            # the objective goes down
+    ck = os.path.join(cfg["train_config"]["out_dir"], "rope", "checkpoints")
+    assert sorted(os.listdir(ck)) == ["latest.pth", "latest_optim.pth", "model_10.pth"]
+    sd = torch.load(os.path.join(ck, "model_10.pth"), map_location="cpu")
+    assert len(sd) == 22
+    eng = DynamicsPredictor(cfg["model_config"], cfg["material_config"], cfg["dataset_config"], DEV)
+    eng.load_state_dict(sd)                                                   # trained weights drop into the fused engine

@@ -437,6 +437,75 @@ def gen_evalrollout(R):
              next_skip=np.asarray(nxt_skip, np.int64), error_short=np.loadtxt(os.path.join(out_dir, "error_short.txt")), **errs)
 
 
+# ------------------------------------------------------------------ training unroll ("next" row n4)
+def gen_train(R):
+    import contextlib
+    import importlib
+    import io
+    import tempfile
+    from adaptigraph_amd import sampling
+    dgraph = importlib.import_module("dynamics.dataset.graph")
+    dgraph.farthest_point_sampler = lambda x, n, start_idx=0: torch.from_numpy(sampling.farthest_point_sampler(x.numpy(), n, start_idx))
+    dds = importlib.import_module("dynamics.dataset.dataset")
+    fx = dict(np.load(os.path.join(OUT, "evalrollout_rope.npz")))      # the synthetic on-disk dataset of row n3
+    dyn, _ = load_cfg("rope")
+    n_future = dyn["dataset_config"]["n_future"]
+    with tempfile.TemporaryDirectory() as root:
+        write_eval_dataset(root, fx)
+        ds = dict(dyn["dataset_config"], data_dir=os.path.join(root, "sim_data"), prep_data_dir=os.path.join(root, "preprocess"),
+                  device="cpu", ratio={"train": [0, 0.67], "valid": [0.67, 1.0]}, verbose=False)
+        ds["datasets"] = [dict(ds["datasets"][0], max_nobj=40, max_nR=400)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            dset = dds.DynDataset(ds, dyn["material_config"], phase="train")
+        out = dict(seed=np.int64(7), idx=np.array([3, 20, 41], np.int64), n_samples=np.int64(len(dset)),
+                   state_noise=np.float64(ds["randomness"]["state_noise"]["train"]))
+        samples = []
+        for k, i in enumerate(out["idx"]):
+            np.random.seed(int(out["seed"]) + k)
+            samples.append(dset[int(i)])
+        keys = ["state", "action", "eef_future", "action_future", "state_future", "attrs", "p_instance", "obj_mask", "rope_physics_param"]
+        batch = {k: torch.stack([s[k] for s in samples]) for k in keys + ["Rr", "Rs", "p_rigid", "material_index"]}
+        for k in keys:
+            out["b_" + k] = batch[k].numpy()
+        # edges as lists (dense Rr/Rs would be 3 x 400 x 41 x 2)
+        n_rel = [int((s["Rr"].sum(1) > 0).sum()) for s in samples]
+        cap = max(n_rel)
+        recv, send = np.zeros((3, cap), np.int32), np.zeros((3, cap), np.int32)
+        for b, s in enumerate(samples):
+            recv[b, :n_rel[b]] = s["Rr"][:n_rel[b]].argmax(1).numpy()
+            send[b, :n_rel[b]] = s["Rs"][:n_rel[b]].argmax(1).numpy()
+        out.update(n_rel=np.array(n_rel, np.int32), recv=recv, send=send)
+        # the objective of train.py:84-108 and its gradients, on the reference model with seed-0 weights
+        model = build_model(R, "rope")
+        model.train()
+        data = {k: v.clone() for k, v in batch.items()}
+        mse = torch.nn.MSELoss()
+        loss_sum, preds = 0, []
+        for fi in range(n_future):
+            gt_state = data["state_future"][:, fi].clone()
+            pred_state, pred_motion = model(**data)
+            pred_state_p = pred_state[:, :gt_state.shape[1], :3].clone()
+            preds.append(pred_state_p.detach().numpy())
+            loss_sum = loss_sum + mse(pred_state_p, gt_state)
+            if fi < n_future - 1:
+                next_eef = data["eef_future"][:, fi].clone()
+                next_action = data["action_future"][:, fi].clone()
+                next_state = next_eef.unsqueeze(1)
+                next_state[:, -1, :pred_state_p.shape[1]] = pred_state_p
+                data["state"] = torch.cat([data["state"][:, 1:], next_state], dim=1)
+                data["action"] = next_action
+        loss_sum.backward()
+        out["loss"] = np.float64(loss_sum.item())
+        out["preds"] = np.stack(preds)
+        for k, p in model.named_parameters():
+            out["grad_" + k] = p.grad.numpy()
+        # one Adam step as train.py does it (lr 1e-3): the updated first-layer weights pin the optimiser settings
+        opt = torch.optim.Adam(model.parameters(), lr=0.001)
+        opt.step()
+        out["adam_particle_encoder.model.0.weight"] = model.state_dict()["particle_encoder.model.0.weight"].numpy()
+        save("train_rope", **out)
+
+
 def R_load(ds, material_config):
     import contextlib
     import importlib
@@ -455,6 +524,8 @@ def main():
         return gen_sysid(R)
     if len(sys.argv) > 1 and sys.argv[1] == "evalrollout":
         return gen_evalrollout(R)
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        return gen_train(R)
     gen_weights(R)
     gen_edges(R)
     gen_forward(R)
@@ -462,6 +533,7 @@ def main():
     gen_mppi(R)
     gen_sysid(R)
     gen_evalrollout(R)
+    gen_train(R)
 
 
 if __name__ == "__main__":
