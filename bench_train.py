@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Side benchmark for the training path: wall-clock of one optimisation step of the reference's
+training objective (n_future = 3 unrolled forward passes + backward + Adam) at the reference's training shape
+(config/dynamics/rope.yaml: batch 128, <= 100 key-points + 1 tool per graph, <= 1000 relations), on one MI355X.
+
+    python bench_train.py [--batch 128] [--steps 20] [--warmup 5] [--dense-baseline]
+
+`value` times `TrainableDynamicsPredictor` (CSR gather / segment-reduce HIP kernels + library GEMMs).  With
+--dense-baseline the same step is also timed in the reference's formulation — one-hot Rr/Rs matrices and `bmm`, restated
+here in plain torch on the same GPU (`baseline_dense_bmm_ms`) — with the loss of both checked to agree.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from adaptigraph_amd import configs, graph as aggraph                          # noqa: E402
+from adaptigraph_amd.train_model import TrainableDynamicsPredictor, unrolled_loss   # noqa: E402
+from adaptigraph_amd.train_ops import EdgeViews                                 # noqa: E402
+
+
+def synthetic_batch(B, n_obj_max, dev, seed=0):
+    """Rope-like key-point clouds with 60-100 valid points per sample, padded to n_obj_max + 1 tool slot."""
+    rng = np.random.default_rng(seed)
+    N = n_obj_max + 1
+    state = np.zeros((B, 4, N, 3), np.float32)
+    mask = np.zeros((B, N), bool)
+    for b in range(B):
+        n = int(rng.integers(60, n_obj_max + 1))
+        i = np.arange(n)
+        cur = np.stack([i * 0.2, np.zeros(n), 2.0 * np.sin(2 * np.pi * i / n)], 1) + rng.normal(0, 0.02, (n, 3))
+        for h in range(4):
+            state[b, h, :n] = cur + rng.normal(0, 0.01, (n, 3)) * (3 - h)
+            state[b, h, -1] = [cur[n // 2, 0], 0.0, cur[n // 2, 2] + 0.3 - 0.05 * (3 - h)]
+        mask[b, :n] = True
+        mask[b, -1] = True
+    tool = np.zeros((B, N), bool)
+    tool[:, -1] = True
+    attrs = np.zeros((B, N, 2), np.float32)
+    attrs[..., 0] = mask & ~tool
+    attrs[..., 1] = tool
+    action = np.zeros((B, N, 3), np.float32)
+    action[:, -1] = [0.0, 0.0, 0.05]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = {"state": t(state), "attrs": t(attrs), "action": t(action), "p_instance": t(attrs[:, :n_obj_max, :1].copy()),
+            "rope_physics_param": torch.full((B, 1), 0.5, device=dev),
+            "state_future": t(state[:, -1:, :n_obj_max].repeat(3, 1) + rng.normal(0, 0.02, (B, 3, n_obj_max, 3)).astype(np.float32)),
+            "eef_future": t(np.repeat(state[:, -1:], 2, 1) * tool[:, None, :, None]), "action_future": t(np.repeat(action[:, None], 2, 1))}
+    csr = aggraph.build_edges(t(state[:, -1]), 0.5, t(mask), t(tool), 10, False, "single", max_tools=1)
+    return data, csr
+
+
+def dense_forward(model, state, attrs, Rr, Rs, p_instance, action, phys):
+    """The reference formulation (model.py:129-313): one-hot relation matrices and bmm."""
+    B, N = attrs.shape[:2]
+    n_p = p_instance.shape[1]
+    Rr_t = Rr.transpose(1, 2)
+    sn = torch.cat([state[:, 1:] - state[:, :-1], state[:, -1:]], 1).transpose(1, 2).reshape(B, N, -1)
+    ph = torch.cat([phys[:, None].expand(B, n_p, -1), phys.new_zeros(B, N - n_p, phys.shape[1])], 1)
+    p_in = torch.cat([attrs, ph, action], 2)
+    g = torch.cat([p_instance, p_instance.new_zeros(B, N - n_p, 1)], 1)
+    rel = torch.cat([Rr.bmm(attrs), Rs.bmm(attrs), (Rr.bmm(g) - Rs.bmm(g)).abs().sum(2, keepdim=True), Rr.bmm(sn) - Rs.bmm(sn)], 2)
+    mlp = lambda blk, x: F.relu(blk.model[4](F.relu(blk.model[2](F.relu(blk.model[0](x))))))
+    enc_n, enc_e = mlp(model.particle_encoder, p_in), mlp(model.relation_encoder, rel)
+    h = enc_n
+    for _ in range(model.model_config["pstep"]):
+        eff = F.relu(model.relation_propagator.linear(torch.cat([enc_e, Rr.bmm(h), Rs.bmm(h)], 2)))
+        h = F.relu(model.particle_propagator.linear(torch.cat([enc_n, Rr_t.bmm(eff)], 2)) + h)
+    d = model.non_rigid_predictor
+    m = d.linear_2(F.relu(d.linear_1(F.relu(d.linear_0(h[:, :n_p])))))
+    return state[:, -1, :n_p] + m.clamp(-100, 100)
+
+
+def dense_unrolled_loss(model, data, Rr, Rs, n_future=3):
+    state, action, loss = data["state"], data["action"], 0
+    for fi in range(n_future):
+        pred = dense_forward(model, state, data["attrs"], Rr, Rs, data["p_instance"], action, data["rope_physics_param"])
+        loss = loss + F.mse_loss(pred, data["state_future"][:, fi])
+        if fi < n_future - 1:
+            nxt = data["eef_future"][:, fi].clone()
+            nxt[:, :pred.shape[1]] = pred
+            state, action = torch.cat([state[:, 1:], nxt[:, None]], 1), data["action_future"][:, fi]
+    return loss
+
+
+def timed(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--max-nobj", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dense-baseline", action="store_true")
+    a = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_train.py needs an MI355X: the graph kernels have no CPU path")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = TrainableDynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), dev).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    data, csr = synthetic_batch(a.batch, a.max_nobj, dev)
+    data.update(Rr=csr, Rs=None, edge_views=EdgeViews(csr))
+
+    def step():
+        opt.zero_grad()
+        loss = unrolled_loss(model, data, 3)
+        loss.backward()
+        opt.step()
+        return loss
+
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    ms, _ = timed(step, a.steps, a.warmup)
+    line = {"metric": "training step wall-clock (3-step unroll forward + backward + Adam)", "value": round(ms, 3), "unit": "ms", "n_gpus": 1,
+            "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"rope key-point graphs, batch {a.batch}, <= {a.max_nobj}+1 nodes, {int(csr.n_rel().sum())} edges in the batch"},
+            "graphs_per_s": round(a.batch / ms * 1e3, 1)}
+    if a.dense_baseline:
+        Rr, Rs = csr.to_dense(torch.float32)
+        model.load_state_dict(init)
+        l_csr = unrolled_loss(model, data, 3).item()
+        l_dense = dense_unrolled_loss(model, data, Rr, Rs).item()
+        assert abs(l_csr - l_dense) <= 1e-5 * max(1.0, abs(l_dense)), (l_csr, l_dense)
+        opt2 = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+        def dense_step():
+            opt2.zero_grad()
+            loss = dense_unrolled_loss(model, data, Rr, Rs)
+            loss.backward()
+            opt2.step()
+            return loss
+
+        ms_d, _ = timed(dense_step, a.steps, a.warmup)
+        line.update(baseline_dense_bmm_ms=round(ms_d, 3), speedup_vs_dense_bmm=round(ms_d / ms, 2), loss_check=[l_csr, l_dense])
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
