@@ -651,13 +651,15 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
     ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 16, 0, 0, lds};
     pipe_start(P);
     TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
+#if AG_TRACE
     int it = -1;
+#endif
 #pragma unroll 1
     while (q.tile < ntiles) {
         const int tile = q.tile;
         q.claim();
-        ++it;
 #if AG_TRACE
+        ++it;
         {   // record the 6th row tile of wave 0 in blocks 0, 1, 256, 257
             const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 256 ? 2 : blockIdx.x == 257 ? 3 : -1;
             P.tr = (it == 5 && slot >= 0 && wave == 0) ? 0 : -1;
