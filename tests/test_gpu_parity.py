@@ -242,6 +242,32 @@ def test_forward_translation_invariance(model):
     assert (m0 - m1).abs().max().item() <= 4e-5
 
 
+def test_forward_permutation_equivariance(model, prec):
+    """Relabelling the object particles permutes the outputs and changes nothing else (permutation
+    invariance).  The edge SET is the same up to relabelling; only the order in which a receiver's messages are summed
+    changes, so equality is to rounding, and the rebuilt edge lists are compared exactly."""
+    g = synth.make_graph_inputs("rope", 150, 2, seed=4, spacing=0.1)
+    n_p = g["p_instance"].shape[1]
+    rng = np.random.default_rng(0)
+    perm = np.concatenate([rng.permutation(n_p), np.arange(n_p, g["attrs"].shape[1])])      # tools stay in the trailing slots
+    inv = np.argsort(perm)
+    kw = dict(rope_physics_param=t(g["phys"]))
+
+    def run(state, attrs, action, p_instance, mask, tool):
+        csr = aggraph.build_edges(t(state[:, -1]), 0.5, t(mask), t(tool), 10, False, "batch", max_tools=1)
+        pos, mot = model(t(state), t(attrs), csr, None, t(p_instance), action=t(action), **kw)
+        return csr, pos.cpu().numpy(), mot.cpu().numpy()
+
+    csr0, pos0, mot0 = run(g["state"], g["attrs"], g["action"], g["p_instance"], g["mask"], g["tool_mask"])
+    csr1, pos1, mot1 = run(g["state"][:, :, perm], g["attrs"][:, perm], g["action"][:, perm], g["p_instance"][:, perm[:n_p]],
+                           g["mask"][:, perm], g["tool_mask"][:, perm])
+    for (r0, s0), (r1, s1) in zip(csr0.to_lists(), csr1.to_lists()):
+        assert sorted(zip(r0.tolist(), s0.tolist())) == sorted(zip(perm[r1].tolist(), perm[s1].tolist()))
+    tol = 2 * TOL_BY_PREC[prec]
+    assert np.abs(mot1 - mot0[:, perm[:n_p]]).max() <= tol and np.abs(pos1 - pos0[:, perm[:n_p]]).max() <= tol
+    assert inv[perm[3]] == 3
+
+
 # ------------------------------------------------------------------------------------------ rollout drivers
 # Multi-step rollouts rebuild the radius/top-k graph from PREDICTED positions every step, so arithmetic that is not
 # bit-identical to the reference's (any GPU, any summation order) can flip an edge whose two candidate distances
