@@ -315,7 +315,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            m->max_blocks = 2 * prop.multiProcessorCount;
+            m->max_blocks = AG_MLP_WG_PER_CU * prop.multiProcessorCount;
         if (const char *v = getenv("AG_MAX_BLOCKS")) m->max_blocks = atoi(v);
     }
     const int rc = pack_and_upload(m, weights);

@@ -24,8 +24,12 @@
 #define AG_CHUNK_FLOATS 5120 // 32 out-features x 160 = 1280 float4 = 5 per thread of a 256-thread block
 #define AG_CHUNK_F4 1280
 #define AG_ROWS_PER_WAVE 32
-#define AG_MLP_THREADS 256
-#define AG_ROWS_PER_BLOCK 128
+#ifndef AG_MLP_THREADS
+#define AG_MLP_THREADS 256      // threads per MLP workgroup (256: two workgroups per CU; 512: one, sharing one weight ring)
+#endif
+#define AG_MLP_WAVES (AG_MLP_THREADS / 64)
+#define AG_ROWS_PER_BLOCK (32 * AG_MLP_WAVES)
+#define AG_MLP_WG_PER_CU (512 / AG_MLP_THREADS)
 #define AG_PACK_BLOCK (32 * AG_FP)
 #define AG_NHIS 4            // n_his compiled into the edge-feature prologue (config/dynamics/*.yaml n_his: 4)
 #define AG_ATTR 2            // attr_dim = rel_attr_dim = 2

@@ -131,7 +131,9 @@ __device__ __forceinline__ void pipe_dma(ChunkPipe &P, int buf)
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)P.lds;
     const unsigned dst = __builtin_amdgcn_readfirstlane(base + (buf * AG_CHUNK_FLOATS + (threadIdx.x >> 6) * 256) * 4);
 #pragma unroll
-    for (int u = 0; u < 5; ++u) dma16(g + 256 * u, dst + 4096 * u);
+    for (int u = 0; u * AG_MLP_THREADS < AG_CHUNK_F4; ++u)        // 1280 float4 per chunk: 5 pieces per wave at 256 threads, 3 / 2 at 512
+        if ((u + 1) * AG_MLP_THREADS <= AG_CHUNK_F4 || (int)threadIdx.x + u * AG_MLP_THREADS < AG_CHUNK_F4)   // wave-uniform (64 | 1280)
+            dma16(g + AG_MLP_THREADS * u, dst + 16 * AG_MLP_THREADS * u);
     P.fetch = P.fetch + 1 == P.total ? 0 : P.fetch + 1;
 }
 
@@ -581,7 +583,7 @@ template <> __device__ __forceinline__ const float4 *pick<PrecB3>(const float4 *
 //          relation_propagator applied at NODE level instead of per edge, model.py:283-289)
 // ---------------------------------------------------------------------------------------------
 template <class Prec>
-__global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeights w, AgFwdArgs a)
+__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
         }
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
-        const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
+        const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         dense_first<Prec, AG_NODE_IN_MAX>(P, x, y);
         q.publish();
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_encode_kernel(AgWeight
 // The one-hot gathers Rr.bmm / Rs.bmm become indexed reads of the (L2-resident) raw node inputs.
 // ---------------------------------------------------------------------------------------------
 template <class Prec>
-__global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
+__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void edge_encode_kernel(AgWeight
 // or — after the last round — the decoder + clamp + integrate (model.py:306-309).
 // ---------------------------------------------------------------------------------------------
 template <class Prec, bool LAST>
-__global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeights w, AgFwdArgs a)
+__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, 2) void node_update_kernel(AgWeight
 #pragma unroll
             for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
         }
-        const size_t blk = (size_t)(tile * 4 + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
+        const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         if (!LAST) {
             dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
