@@ -32,26 +32,31 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     const int g = logical * kNodesPerBlock + slot;
     if (g >= a.B * a.N) return;
     const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
+    constexpr int kFly = 4;   // edges in flight per lane, sender indices fetched one iteration ahead (see aggregate_half_kernel)
+    int s[kFly];
+#pragma unroll
+    for (int i = 0; i < kFly; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
     const float4 hr = *reinterpret_cast<const float4 *>(a.hr + (size_t)g * AG_FP + 4 * c);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int e = e0;
-    for (; e + 1 < e1; e += 2) {   // two edges in flight per lane
-        const int s0 = a.edge_send[e], s1 = a.edge_send[e + 1];
-        const float4 t0 = *reinterpret_cast<const float4 *>(a.eterm + (size_t)e * AG_FP + 4 * c);
-        const float4 t1 = *reinterpret_cast<const float4 *>(a.eterm + (size_t)(e + 1) * AG_FP + 4 * c);
-        const float4 u0 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + 4 * c);
-        const float4 u1 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s1 * AG_FP + 4 * c);
-        acc.x += fmaxf((t0.x + hr.x) + u0.x, 0.f); acc.y += fmaxf((t0.y + hr.y) + u0.y, 0.f);
-        acc.z += fmaxf((t0.z + hr.z) + u0.z, 0.f); acc.w += fmaxf((t0.w + hr.w) + u0.w, 0.f);
-        acc.x += fmaxf((t1.x + hr.x) + u1.x, 0.f); acc.y += fmaxf((t1.y + hr.y) + u1.y, 0.f);
-        acc.z += fmaxf((t1.z + hr.z) + u1.z, 0.f); acc.w += fmaxf((t1.w + hr.w) + u1.w, 0.f);
-    }
-    if (e < e1) {
-        const int s0 = a.edge_send[e];
-        const float4 t0 = *reinterpret_cast<const float4 *>(a.eterm + (size_t)e * AG_FP + 4 * c);
-        const float4 u0 = *reinterpret_cast<const float4 *>(a.hs + (size_t)s0 * AG_FP + 4 * c);
-        acc.x += fmaxf((t0.x + hr.x) + u0.x, 0.f); acc.y += fmaxf((t0.y + hr.y) + u0.y, 0.f);
-        acc.z += fmaxf((t0.z + hr.z) + u0.z, 0.f); acc.w += fmaxf((t0.w + hr.w) + u0.w, 0.f);
+    for (int e = e0; e < e1; e += kFly) {
+        int sn[kFly];
+#pragma unroll
+        for (int i = 0; i < kFly; ++i) sn[i] = e + kFly + i < e1 ? a.edge_send[e + kFly + i] : -1;
+        float4 t[kFly], u[kFly];
+#pragma unroll
+        for (int i = 0; i < kFly; ++i)
+            if (s[i] >= 0) {
+                t[i] = *reinterpret_cast<const float4 *>(a.eterm + (size_t)(e + i) * AG_FP + 4 * c);
+                u[i] = *reinterpret_cast<const float4 *>(a.hs + (size_t)s[i] * AG_FP + 4 * c);
+            }
+#pragma unroll
+        for (int i = 0; i < kFly; ++i)
+            if (s[i] >= 0) {
+                acc.x += fmaxf((t[i].x + hr.x) + u[i].x, 0.f); acc.y += fmaxf((t[i].y + hr.y) + u[i].y, 0.f);
+                acc.z += fmaxf((t[i].z + hr.z) + u[i].z, 0.f); acc.w += fmaxf((t[i].w + hr.w) + u[i].w, 0.f);
+            }
+#pragma unroll
+        for (int i = 0; i < kFly; ++i) s[i] = sn[i];
     }
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + 4 * c) = acc;
 }
