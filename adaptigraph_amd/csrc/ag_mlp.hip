@@ -137,38 +137,28 @@ __device__ __forceinline__ void pipe_dma(ChunkPipe &P, int buf)
     P.fetch = P.fetch + 1 == P.total ? 0 : P.fetch + 1;
 }
 
-// Drain the LDS-DMA of the next chunk before the tile's barrier.  vmcnt retires in order and (on gfx9/CDNA) counts
-// stores too, and the only vector-memory ops a tile issues AFTER its DMA that may still be pending here are the S
-// stores of its own epilogue — so vmcnt(S) waits for the copy without also waiting ~1-2 us for those stores.
-template <int S>
-__device__ __forceinline__ void pipe_wait()
-{
-    static_assert(S >= 0 && S <= 4, "epilogue store count");
-    if (S == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (S == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (S == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (S == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-}
+// Drain the LDS-DMA of the next chunk before the tile's barrier: a full `vmcnt(0)`.  A counted wait that leaves the
+// tile's own epilogue stores in flight (vmcnt(S)) measured the same in the split-bf16 kernels (their epilogue is deferred
+// by a tile, so the stores are ~1 us old here) and 1.5 % faster in one exact-fp32 kernel, but it is only correct if a
+// younger store can never retire before an older load; LLVM's own waitcnt pass does not assume that on gfx9-class
+// targets (mixed load/store events make the counter "out of order"), so neither does this code.
+__device__ __forceinline__ void pipe_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void pipe_start(ChunkPipe &P)
 {
     pipe_dma(P, 0);         // chunk 0
-    pipe_wait<0>();
+    pipe_wait();
     __syncthreads();
 }
 
 // ---- per-tile epilogues (run right after a 32-feature out-tile is finished, so its stores overlap the next
 //      tile's MFMAs instead of piling up behind the layer) -------------------------------------------------
 struct NoEpi {
-    static constexpr int kStores = 0;
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
 };
-// NB: epilogue stores are UNCONDITIONAL (a row past the valid range writes into the table's padding rows, every
-// table is allocated in whole 128-row tiles): pipe_wait<kStores> relies on every wave having issued exactly
-// kStores vector-memory ops after its DMA, whether or not its rows are valid.
+// Epilogue stores are unconditional: a row past the valid range writes into the table's padding rows (every table is
+// allocated in whole row tiles), which keeps the epilogue branch-free.
 struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row = table + row*160 + 4h
-    static constexpr int kStores = 4;
     float *row;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
@@ -178,7 +168,6 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
     }
 };
 struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
-    static constexpr int kStores = 2;
     _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
@@ -191,7 +180,6 @@ struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles]
     }
 };
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
-    static constexpr int kStores = 4;
     float *blk_lane;
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
@@ -278,7 +266,7 @@ struct PrecF32 {
             }
             epi(ti, acc);
             sink(ti, acc);
-            pipe_wait<Epi::kStores>();
+            pipe_wait();
             __syncthreads();
             P.buf ^= 1;
         }
@@ -312,7 +300,7 @@ struct PrecF32 {
             for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
             sink(ti, acc);
         }
-        pipe_wait<0>();
+        pipe_wait();
         __syncthreads();
         P.buf ^= 1;
     }
@@ -399,7 +387,7 @@ struct PrecB3 {
             });
             prev = acc;
             AG_STAMP(P);
-            if (!(AG_ABL & 16)) { if (ti == 0) pipe_wait<0>(); else pipe_wait<Epi::kStores>(); }
+            if (!(AG_ABL & 16)) pipe_wait();
             AG_STAMP(P);
             if (!(AG_ABL & 2)) __syncthreads();
             AG_STAMP(P);
@@ -449,7 +437,7 @@ struct PrecB3 {
             for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
             sink(ti, acc);
         });
-        pipe_wait<0>();
+        pipe_wait();
         __syncthreads();
         P.buf ^= 1;
     }
