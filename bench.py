@@ -204,12 +204,13 @@ def main():
             "metric": "rollout graph-steps/s (batch x rollout steps / wall; edge build + GNN forward + state update per graph-step)",
             "value": B_global * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
             "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {args.batch}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
                                    f"{args.material} {wl['n_obj']} particles, batch {args.batch}/GPU, {T}-step rollout",
                        "global_batch": B_global, "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather", "rollout_streams": args.streams,
-                       "weights": "seed-0 random init (reference default init)", "precision": args.precision},
+                       "weights": "seed-0 random init (reference default init)", "precision": args.precision,
+                       "arithmetic": DTYPE[args.precision]},
             "roofline": roof, "roofline_hbm": roof_hbm if not args.no_profile else None, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
