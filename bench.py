@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes needs it)
+
 import numpy as np
 import torch
 import torch.distributed as dist
