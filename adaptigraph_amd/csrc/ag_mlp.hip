@@ -84,6 +84,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const void *p)
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
+#ifndef AG_E64_PIN
+#define AG_E64_PIN 1     // sched_barrier(0) after every epilogue-unit slot of the two-block layers (0: leave placement to the compiler)
+#endif
 #ifndef AG_TRACE
 #define AG_TRACE 0      // debug builds only (tools/trace_tiles.py): s_memtime stamps of one wave's tile phases
 #endif
@@ -153,8 +156,11 @@ __device__ __forceinline__ void pipe_start(ChunkPipe &P)
 
 // ---- per-tile epilogues (run right after a 32-feature out-tile is finished, so its stores overlap the next
 //      tile's MFMAs instead of piling up behind the layer) -------------------------------------------------
+// Each epilogue can also be applied in two halves: half s covers accumulator registers 8s..8s+7 of the out-tile (the
+// unit in which the two-block kernels schedule their epilogue work between k16-steps).
 struct NoEpi {
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
+    __device__ __forceinline__ void half(int, int, const f32x16 &) const {}
 };
 // Epilogue stores are unconditional: a row past the valid range writes into the table's padding rows (every table is
 // allocated in whole row tiles), which keeps the epilogue branch-free.
@@ -164,6 +170,12 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
     {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    __device__ __forceinline__ void half(int ti, int s, const f32x16 &v) const
+    {
+#pragma unroll
+        for (int q = 2 * s; q < 2 * s + 2; ++q)
             *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 };
@@ -177,6 +189,14 @@ struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles]
         for (int r = 0; r < 8; ++r) { a[r] = (_Float16)v[r]; b[r] = (_Float16)v[8 + r]; }
         *reinterpret_cast<h8 *>(row + 32 * ti) = a;
         *reinterpret_cast<h8 *>(row + 32 * ti + 8) = b;
+    }
+    __device__ __forceinline__ void half(int ti, int s, const f32x16 &v) const
+    {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 a;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = (_Float16)v[8 * s + r];
+        *reinterpret_cast<h8 *>(row + 32 * ti + 8 * s) = a;
     }
 };
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
@@ -307,6 +327,122 @@ struct PrecF32 {
 };
 
 
+// ---- weight pipeline of the two-block (one wave per SIMD) kernels -----------------------------------------------
+// With ONE wave per SIMD nothing else covers a stall, so the pipeline is deeper than ChunkPipe's:
+//  * FOUR 20 KB LDS buffers.  While chunk c is consumed (buffer c % 4), chunks c+1 and c+2 are resident and certified
+//    (copied, drained by every wave and barriered), and chunk c+3 is being copied into the buffer chunk c-1 left.
+//  * Copies are issued in the second half of a tile and drained in the MIDDLE of the next one, a full tile later
+//    (a drain at the tile end measured ~240 cycles per tile: a 20 KB chunk needs > 1 000 cycles to land when every CU
+//    streams); the tile-end barrier then certifies them, one tile before their first read.
+//  * The fragment-read ring wq runs ACROSS the tile barrier: the first PF k16-steps of chunk c+1 are read during the
+//    last steps of chunk c, so a tile starts with its operands in registers instead of an exposed LDS round trip.
+//    4 slots, so that the slot of a step is a compile-time function of the step count (10 steps per tile, 160 per
+//    row tile = 0 mod 4).
+struct Ring4 {
+    const float4 *g;   // weight stream (global), walked cyclically
+    int total;         // chunks in the stream
+    int fetch;         // next stream chunk to copy
+    int buf;           // ring buffer holding the chunk being consumed (0..3)
+    float *lds;        // 4 * AG_CHUNK_FLOATS
+    bf16x8 wq[4][2];   // [slot][hi|lo]
+#if AG_TRACE
+    int tr = -1, trb = 0;
+#endif
+};
+constexpr int kRingPF = 2;
+#if AG_TRACE   // (tag, s_memtime) pairs, 256 per slot (tools/trace_e64.py)
+#define RING_STAMP(R, TAG) do { if ((R).tr >= 0 && (R).tr < 256) { ag_trace_buf[(R).trb + 2 * (R).tr] = (TAG); ag_trace_buf[(R).trb + 2 * (R).tr + 1] = __builtin_readcyclecounter(); (R).tr++; } } while (0)
+#else
+#define RING_STAMP(R, TAG) do { } while (0)
+#endif
+
+__device__ __forceinline__ unsigned ring_cur(const Ring4 &R, int lane)
+{
+    return lds_addr_of(R.lds) + (unsigned)(R.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+}
+__device__ __forceinline__ unsigned ring_next(const Ring4 &R, int lane)
+{
+    return lds_addr_of(R.lds) + (unsigned)(((R.buf + 1) & 3) * AG_CHUNK_FLOATS * 4 + lane * 16);
+}
+// one 1 KB-per-wave piece (of five) of chunk `fetch` -> buffer (buf + 3) % 4
+__device__ __forceinline__ void ring_dma_piece(Ring4 &R, int piece)
+{
+    int f = R.fetch;
+    asm volatile("" : "+s"(f));     // keep the (cyclic) chunk address out of LICM's reach, as pipe_dma does
+    const float4 *g = R.g + (size_t)f * AG_CHUNK_F4 + threadIdx.x + 256 * piece;
+    const int tb = (R.buf + 3) & 3;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)R.lds;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(base + (tb * AG_CHUNK_FLOATS + (threadIdx.x >> 6) * 256) * 4) + 16 * 256 * piece;
+    dma16(g, dst);
+}
+// k16-step S (of 10) of a chunk: mid-tile, drain the copies issued during the previous tile, then issue this tile's
+__device__ __forceinline__ void ring_feed(Ring4 &R, int S)
+{
+    if (AG_ABL & 4) return;
+    if (S == 5) { if (!(AG_ABL & 16)) pipe_wait(); ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
+    if (S == 6) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
+    if (S == 7) ring_dma_piece(R, 4);
+}
+// end of a chunk: barrier (certifies the copies drained mid-tile), rotate
+__device__ __forceinline__ void ring_advance(Ring4 &R)
+{
+    R.fetch = R.fetch + 1 == R.total ? 0 : R.fetch + 1;
+    RING_STAMP(R, 4);
+    if (!(AG_ABL & 2)) __syncthreads();
+    RING_STAMP(R, 5);
+    R.buf = (R.buf + 1) & 3;
+}
+// k16-step S of a chunk with NS steps whose step 0 sits in ring slot PH: issue the reads of step S + PF (of the NEXT
+// chunk's first steps once S + PF >= NS: standard image offsets, valid for the compact first-layer chunk too), then
+// wait for step S's pair (exactly PF pairs were issued after it).
+template <int PH, int S, int NS>
+__device__ __forceinline__ void ring_step(Ring4 &R, unsigned la, unsigned ln)
+{
+    constexpr int T = S + kRingPF, slot = (PH + T) % 4;
+    if constexpr (T < NS) {
+        lds_read16<(2 * T) * 1024>(R.wq[slot][0], la);
+        lds_read16<(2 * T + 1) * 1024>(R.wq[slot][1], la);
+    } else {
+        lds_read16<(2 * (T - NS)) * 1024>(R.wq[slot][0], ln);
+        lds_read16<(2 * (T - NS) + 1) * 1024>(R.wq[slot][1], ln);
+    }
+    lds_wait_pair<2 * kRingPF>(R.wq[(PH + S) % 4][0], R.wq[(PH + S) % 4][1]);
+}
+// End of a chunk: the PF pairs read ahead for the next chunk must have LANDED before control leaves the straight-line
+// tile body (barrier, layer boundary, loop back-edge): an asm load's destination counts as written at the asm statement,
+// so across a join the register allocator may copy or re-assign it while the LDS return is still in flight (stale
+// fragment, or the late return lands in a register that now holds an address: observed as a memory fault).  They were
+// issued >= 2 k16-steps (12 MFMAs) earlier, so this wait does not stall.  PHN = ring slot of the next chunk's step 0.
+template <int PHN>
+__device__ __forceinline__ void ring_settle(Ring4 &R)
+{
+    static_assert(kRingPF == 2, "two pairs in flight");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(R.wq[PHN % 4][0]), "+v"(R.wq[PHN % 4][1]), "+v"(R.wq[(PHN + 1) % 4][0]), "+v"(R.wq[(PHN + 1) % 4][1]));
+}
+// chunks 0, 1, 2 resident and certified, chunk 0's first PF steps in registers; ring slot phase 0
+__device__ __forceinline__ void ring_start(Ring4 &R)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        R.fetch = c < R.total ? c : 0;
+        R.buf = (c + 1) & 3;                                     // target (buf + 3) % 4 = buffer c
+#pragma unroll
+        for (int p = 0; p < 5; ++p) ring_dma_piece(R, p);
+    }
+    R.fetch = R.total > 3 ? 3 : 0; R.buf = 0;
+    pipe_wait();
+    __syncthreads();
+    const unsigned la = ring_cur(R, lane);
+    static_for<0, kRingPF>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        lds_read16<(2 * u) * 1024>(R.wq[u][0], la);
+        lds_read16<(2 * u + 1) * 1024>(R.wq[u][1], la);
+    });
+    ring_settle<0>(R);
+}
+
 struct PrecB3 {
     // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
     // which is accumulator register 8s + e of out-tile t — so a finished tile converts in place, no shuffles.
@@ -316,21 +452,24 @@ struct PrecB3 {
     // epilogues were co-limiting the kernels with the MFMAs.)
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
     {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) set_half(a, ti, s, v);
+    }
+    // k16-step 2ti + s of the next layer's operand = accumulator registers 8s..8s+7 of out-tile ti
+    __device__ __forceinline__ static void set_half(Act &a, int ti, int s, const f32x16 &v)
+    {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 H, L;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 H, L;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float x0 = v[8 * s + 2 * w], x1 = v[8 * s + 2 * w + 1];
-                const unsigned hp = cvt_pk_bf16(x0, x1);
-                const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
-                H[w] = hp;
-                L[w] = (AG_ABL & 1) ? hp : cvt_pk_bf16(x0 - h0, x1 - h1);
-            }
-            a.hi[2 * ti + s] = __builtin_bit_cast(bf16x8, H);
-            a.lo[2 * ti + s] = __builtin_bit_cast(bf16x8, L);
+        for (int w = 0; w < 4; ++w) {
+            const float x0 = v[8 * s + 2 * w], x1 = v[8 * s + 2 * w + 1];
+            const unsigned hp = cvt_pk_bf16(x0, x1);
+            const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
+            H[w] = hp;
+            L[w] = (AG_ABL & 1) ? hp : cvt_pk_bf16(x0 - h0, x1 - h1);
         }
+        a.hi[2 * ti + s] = __builtin_bit_cast(bf16x8, H);
+        a.lo[2 * ti + s] = __builtin_bit_cast(bf16x8, L);
     }
 
     template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
@@ -440,6 +579,164 @@ struct PrecB3 {
         pipe_wait();
         __syncthreads();
         P.buf ^= 1;
+    }
+
+    // ---- NB row blocks per wave (edge_encode64_kernel: NB = 2, one wave per SIMD, 512 registers) -------------------
+    // Every weight fragment read from LDS feeds NB B-operand blocks (NB x 32 rows), so a chunk image is copied, read
+    // and barriered once per NB x 128 rows of the workgroup: half the L2->LDS DMA bytes, ds_reads and barriers per
+    // MFMA at NB = 2.  Each block keeps its own accumulation chain in the same (lo*hi, hi*lo, hi*hi by ascending k16)
+    // order as `layer`, so a row's result does not depend on which kernel or block computed it.
+    //
+    // Epilogue scheduling.  A finished out-tile leaves 2 x NB half-tile UNITS of epilogue work (ReLU + hi/lo split or
+    // store, ~40 VALU ops each).  A lone wave must issue them in the shadow of its own MFMAs, so every tile body has
+    // four unit SLOTS, after the MFMAs of k16-steps 1, 3, 5 and 7 (3-4 VALU ops per MFMA gap, inside the ~5 a gap hides),
+    // and tile t's units run in tile t+1's slots — across layer boundaries too: `carry(b, s)` finishes the PREVIOUS
+    // layer's last tile in this layer's first tile (its s = 0 / 1 halves are k16-steps 8 / 9 of this layer's input,
+    // first needed after slot 3).  Left to the compiler, whole layers of epilogue sank into the next layer's first
+    // tile (s_memtime: 4 380 cycles for that tile instead of 2 250).  sched_barrier(0) after each slot pins the units.
+    // `prev` holds the unfinished accumulators between tiles and layers; `PH` = ring slot of the call's first k16-step.
+    template <int NB, int K, int NT, bool RELU, bool BIAS, int PH, class Epi, class Sink, class Carry>
+    __device__ __forceinline__ static void layer_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], const Epi (&epi)[NB], Sink &&sink,
+                                                    Carry &&carry)
+    {
+        static_assert(NB == 2, "slot -> (block, half) mapping below");
+        constexpr int KE = K + (BIAS ? 1 : 0);
+        constexpr int NU = (KE + 15) / 16;    // k16-steps per tile
+        static_assert(NU == 10, "ring_feed / unit slots assume 10 k16-steps per chunk");
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        // bias column: activation "feature K" := 1.0 (hi) + 0.0 (lo) for the lane half that holds it, as bit masks (branch-free)
+        constexpr int o = K % 16, be = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
+        const unsigned keep = (BIAS && h == hb) ? ((be & 1) ? 0x0000ffffu : 0xffff0000u) : 0xffffffffu;
+        const unsigned one = (BIAS && h == hb) ? (0x3f80u << (16 * (be & 1))) : 0u;
+        auto unit = [&](int ti, int b, int s) {          // half s of block b of out-tile ti (accumulators in prev)
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) prev[b][8 * s + r] = (AG_ABL & 32) ? prev[b][8 * s + r] : relu1(prev[b][8 * s + r]);
+            }
+            if (!(AG_ABL & 8) || prev[b][0] == 1234.5678f) epi[b].half(ti, s, prev[b]);   // (ablation keeps the value live: no DCE)
+            sink(b, ti, s, prev[b]);
+        };
+        static_for<0, NT>([&](auto T) {
+            constexpr int ti = decltype(T)::value;
+            constexpr int ph = (PH + NU * ti) % 4;
+            const unsigned la = ring_cur(R, lane), ln = ring_next(R, lane);
+            RING_STAMP(R, 1);
+            f32x16 acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                ring_step<ph, u, NU>(R, la, ln);
+                const bf16x8 wh = R.wq[(ph + u) % 4][0], wl = R.wq[(ph + u) % 4][1];
+                bf16x8 xh[NB], xl[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    xh[b] = in[b].hi[u]; xl[b] = in[b].lo[u];
+                    if constexpr (BIAS && K / 16 == u) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 a = __builtin_bit_cast(u32x4, xh[b]), c = __builtin_bit_cast(u32x4, xl[b]);
+                        a[be >> 1] = (a[be >> 1] & keep) | one;
+                        c[be >> 1] = c[be >> 1] & keep;
+                        xh[b] = __builtin_bit_cast(bf16x8, a); xl[b] = __builtin_bit_cast(bf16x8, c);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[b], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[b], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[b], acc[b], 0, 0, 0);
+                ring_feed(R, u);
+                if constexpr ((u & 1) && u < 8) {      // slot (u >> 1): units (b0,s0) (b1,s0) (b0,s1) (b1,s1)
+                    constexpr int slot = u >> 1, ub = slot & 1, us = slot >> 1;
+                    if constexpr (ti > 0) unit(ti - 1, ub, us); else carry(ub, us);
+#if AG_E64_PIN == 2      // ask for an even interleave inside the slot region: 12 x (1 MFMA, 4 VALU)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+                    }
+#endif
+#if AG_E64_PIN
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            });
+            RING_STAMP(R, 2);
+            ring_settle<ph + NU>(R);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) prev[b] = acc[b];
+            ring_advance(R);
+        });
+    }
+    // the units of a layer's LAST tile, for the next layer's `carry` (or run directly after the layer)
+    template <int NT, bool RELU, class Epi, class Sink>
+    __device__ __forceinline__ static void last_unit(f32x16 &pv, const Epi &epi, Sink &&sink, int b, int s)
+    {
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pv[8 * s + r] = (AG_ABL & 32) ? pv[8 * s + r] : relu1(pv[8 * s + r]);
+        }
+        if (!(AG_ABL & 8) || pv[0] == 1234.5678f) epi.half(NT - 1, s, pv);
+        sink(b, NT - 1, s, pv);
+    }
+
+    // compact first layer (ONE chunk for all five out-tiles: [5 tiles][NU][hi|lo] = 10 consecutive k16-step images, so
+    // the fragment ring walks it like an ordinary tile); ReLU, bias column in the features.  Its 20 epilogue units
+    // outnumber its slots (60 MFMAs): out-tile t's four units run behind out-tile t+1's MFMAs, the last tile's are left
+    // in `prev` for the next layer's carry; `carry` finishes the previous ROW TILE's last layer in the first two steps.
+    template <int NB, int K, int PH, class Sink, class Carry>
+    __device__ __forceinline__ static void layer_first_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], Sink &&sink, Carry &&carry)
+    {
+        static_assert(NB == 2, "unit mapping");
+        constexpr int NU = (K + 15) / 16, NS = AG_NT * NU;
+        static_assert(NU == 2, "compact first layer: 10 k16-step images per chunk");
+        const int lane = threadIdx.x & 63;
+        const unsigned la = ring_cur(R, lane), ln = ring_next(R, lane);
+        RING_STAMP(R, 1);
+        f32x16 cur[NB];
+        static_for<0, AG_NT>([&](auto T) {
+            constexpr int ti = decltype(T)::value;
+            f32x16 acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value, st = ti * NU + u;
+                ring_step<PH, st, NS>(R, la, ln);
+                const bf16x8 wh = R.wq[(PH + st) % 4][0], wl = R.wq[(PH + st) % 4][1];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, in[b].hi[u], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].lo[u], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].hi[u], acc[b], 0, 0, 0);
+                ring_feed(R, st);
+                // two units per k16-step: step u of out-tile ti finishes half s = u of both blocks of out-tile ti - 1
+                if constexpr (ti == 0) { carry(0, u); carry(1, u); }
+                else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) cur[b][8 * u + r] = relu1(cur[b][8 * u + r]);
+                        sink(b, ti - 1, u, cur[b]);
+                    }
+                }
+#if AG_E64_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
+#pragma unroll
+            for (int b = 0; b < NB; ++b) cur[b] = acc[b];
+        });
+        RING_STAMP(R, 2);
+        ring_settle<PH + NS>(R);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) prev[b] = cur[b];
+        ring_advance(R);
     }
 };
 
@@ -717,6 +1014,201 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Edge encoder, split-bf16, 64 edges per wave (two 32-row B-operand blocks share every weight fragment) — the r02
+// experiment asked for by the r01 review, kept behind ag_set_option("edge_rows", 64); NOT the default.
+// Same arithmetic as edge_encode_kernel<PrecB3>, bit for bit (tested), but ONE 256-thread workgroup per CU (one wave per
+// SIMD, ~410 registers: the activations of both blocks stay in the unified VGPR/AGPR file), so a 20 KB chunk image serves
+// 256 edges instead of 128: the L2->LDS stream drops from 2 560 to 1 280 B per edge, and so do the fragment ds_reads and
+// barriers per MFMA.  With a single wave per SIMD nothing hides a memory round trip or an epilogue, so the per-edge
+// inputs are fetched split-phase one row tile ahead, the weight ring is four deep with fragments read across the tile
+// barrier, and the epilogue runs in explicit half-tile units pinned between k16-steps (see PrecB3::layer_nb).
+// Measured (C2, profiles/r02_edge64_*.txt): 0.847 ms per launch vs 0.843 for the 32-row kernel solo, and 99.0 k vs
+// 102.4 k graph-steps/s in the two-stream rollout (a 512-register workgroup owns its CU, so the other stream's HBM-bound
+// kernels cannot co-reside).  Why it does not win: the MFMA pipe-time floor is 1.155 M cycles per launch = 0.58-0.61 ms at
+// the 1.9-2.05 GHz the chip sustains under this load; the lone wave must also issue ~200 VALU epilogue ops + 20 ds_reads
+// + 5 DMA pieces per 60 MFMAs in its own MFMA shadow (s_memtime: 2 250-2 700 cycles per 1 920-cycle tile), and the
+// row-tile prologue (gathers, first layer: 60 MFMAs against 800 epilogue VALU ops) is exposed: 64 % pipe-busy vs 70 %
+// for two waves per SIMD — and a higher busy fraction is paid back as a lower clock (DVFS).
+// ---------------------------------------------------------------------------------------------
+#define AG_E64_ROWS 256   // edges per workgroup row tile (4 waves x 2 blocks x 32)
+
+struct EdgeRaw {           // raw gathered inputs of one edge (receiver r, sender s), model.py:220-253
+    float ar[2], as[2], gr, gs;
+    float pr[AG_NHIS][3], ps[AG_NHIS][3];
+    int ri, si, b;
+};
+
+__device__ __forceinline__ void edge_gather(const AgFwdArgs &a, int r, int s, EdgeRaw &g)
+{
+    const int b = r / a.N, ri = r - b * a.N, si = s - b * a.N;
+    g.ri = ri; g.si = si; g.b = b;
+    g.ar[0] = a.attrs[(size_t)r * 2]; g.ar[1] = a.attrs[(size_t)r * 2 + 1];
+    g.as[0] = a.attrs[(size_t)s * 2]; g.as[1] = a.attrs[(size_t)s * 2 + 1];
+    // instance 0 of g = cat([p_instance, 0]) (model.py:235); further instances are read in edge_features
+    g.gr = (a.n_inst > 0 && ri < a.n_p) ? a.p_instance[((size_t)b * a.n_p + ri) * a.n_inst] : 0.0f;
+    g.gs = (a.n_inst > 0 && si < a.n_p) ? a.p_instance[((size_t)b * a.n_p + si) * a.n_inst] : 0.0f;
+    const float *st = a.state + (size_t)b * AG_NHIS * a.N * 3;
+#pragma unroll
+    for (int hh = 0; hh < AG_NHIS; ++hh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g.pr[hh][c] = st[((size_t)hh * a.N + ri) * 3 + c];
+            g.ps[hh][c] = st[((size_t)hh * a.N + si) * 3 + c];
+        }
+}
+
+// rel_inputs = [attrs_r | attrs_s | sum|g_r - g_s| | state_res_r - state_res_s | cur_r - cur_s | 1]; lane half h keeps
+// features 8q + 4h + p (the B-operand image of k16-steps 0 and 1)
+__device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw &g, int h, f32x16 &in0)
+{
+    float feat[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
+    feat[0] = g.ar[0]; feat[1] = g.ar[1]; feat[2] = g.as[0]; feat[3] = g.as[1];
+    float gd = fabsf(g.gr - g.gs);
+    for (int ii = 1; ii < a.n_inst; ++ii) {
+        const float gr = g.ri < a.n_p ? a.p_instance[((size_t)g.b * a.n_p + g.ri) * a.n_inst + ii] : 0.0f;
+        const float gs = g.si < a.n_p ? a.p_instance[((size_t)g.b * a.n_p + g.si) * a.n_inst + ii] : 0.0f;
+        gd += fabsf(gr - gs);
+    }
+    feat[4] = gd;
+    feat[AG_EDGE_IN] = 1.0f;   // bias column of relation_encoder.model.0
+#pragma unroll
+    for (int hh = 0; hh + 1 < AG_NHIS; ++hh)   // state_res = state[:,1:] - state[:,:-1]  (model.py:155)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) feat[5 + hh * 3 + c] = (g.pr[hh + 1][c] - g.pr[hh][c]) - (g.ps[hh + 1][c] - g.ps[hh][c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) feat[5 + (AG_NHIS - 1) * 3 + c] = g.pr[AG_NHIS - 1][c] - g.ps[AG_NHIS - 1][c];
+#pragma unroll
+    for (int r16 = 0; r16 < 16; ++r16) in0[r16] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
+}
+
+template <bool HALF>     // HALF: Eterm is the fp16 table of precision mode 2
+__global__ __launch_bounds__(256, 1) void edge_encode64_kernel(AgWeights w, AgFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * AG_CHUNK_FLOATS];
+    __shared__ int s_next_tile[2];
+    typedef PrecB3 Prec;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int Mn = a.B * a.N;
+    const int E = a.row_ptr[Mn];
+    if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
+    const int ntiles = (E + AG_E64_ROWS - 1) / AG_E64_ROWS;
+    if ((int)blockIdx.x >= ntiles) return;
+    // Row tiles are claimed from the per-launch counter TWO ahead (cur is being computed, nxt is being fetched, the
+    // claim in flight is the one after): the claimed index travels through LDS under the layers' own barriers.
+    int cur = blockIdx.x;
+    if (tid == 0) s_next_tile[0] = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
+    Ring4 P;
+    P.g = w.edge_encode_b3; P.total = 16; P.fetch = 0; P.lds = lds;
+    ring_start(P);                                   // (barrier: s_next_tile[0] is visible)
+    int nxt = s_next_tile[0], par = 1;
+
+    auto edge_of = [&](int tile, int blk) { return tile * AG_E64_ROWS + wave * 64 + blk * 32 + j; };
+    f32x16 in0[2];
+    {
+        EdgeRaw g[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int e = edge_of(cur, blk);
+            const bool valid = e < E;
+            edge_gather(a, valid ? a.edge_recv[e] : 0, valid ? a.edge_send[e] : 0, g[blk]);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) edge_features(a, g[blk], h, in0[blk]);
+    }
+    // Eterm row of (tile, block): fp16 table in precision mode 2 (320-B rows, accumulator order), fp32 otherwise
+    typedef std::conditional_t<HALF, RowStoreHalfEpi, RowStoreEpi> EtermEpi;
+    auto eterm_row = [&](int tile, int blk) {
+        const size_t e = (size_t)edge_of(tile, blk);
+        if constexpr (HALF) return EtermEpi{reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h};
+        else return EtermEpi{a.eterm + e * AG_FP + 4 * h};
+    };
+    f32x16 prev[2];                 // unfinished accumulators of the last out-tile (between tiles, layers and row tiles)
+    EtermEpi pend[2] = {{nullptr}, {nullptr}};    // Eterm rows of the previous row tile's last out-tile
+    bool have_pend = false;
+    auto nosink = [](int, int, int, const f32x16 &) {};
+#if AG_TRACE
+    int it = -1;
+#endif
+#pragma unroll 1
+    while (cur < ntiles) {
+#if AG_TRACE
+        ++it;
+        {   // record the 6th row tile of wave 0 in blocks 0, 1, 128, 129
+            const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 128 ? 2 : blockIdx.x == 129 ? 3 : -1;
+            P.tr = (it == 5 && slot >= 0 && wave == 0) ? 0 : -1;
+            P.trb = (slot < 0 ? 0 : slot) * 512;
+        }
+#endif
+        RING_STAMP(P, 10);
+        int claimed = 0;
+        if (tid == 0) claimed = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
+        // phase 1 of the next row tile's inputs: edge indices (land under the first layer)
+        int nr[2], ns[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int e = edge_of(nxt, blk);
+            const bool valid = e < E;
+            nr[blk] = valid ? a.edge_recv[e] : 0;
+            ns[blk] = valid ? a.edge_send[e] : 0;
+        }
+        typename Prec::Act x[2], y[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) Prec::set_tile(x[blk], 0, in0[blk]);
+        // The empty volatile asm pins a unit's result to its slot: pure VALU code has no ordering against the asm
+        // statements (fragment reads, waits, DMA) that mark the k16-steps, and instruction selection otherwise sinks it
+        // to its first use, a whole layer later.
+        auto pin = [](typename Prec::Act &t, int k) { asm volatile("" : "+v"(t.hi[k]), "+v"(t.lo[k])); };
+        auto to_y = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(y[blk], ti, s, v); pin(y[blk], 2 * ti + s); };
+        auto to_x = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(x[blk], ti, s, v); pin(x[blk], 2 * ti + s); };
+        const NoEpi noepi[2] = {};
+        // fragment-ring phases: 10 k16-steps (first layer) + 3 x 50 per row tile: 0 -> 2 -> 0 -> 2 -> 0 (mod 4)
+        Prec::template layer_first_nb<2, AG_EDGE_IN + 1, 0>(P, x, prev, to_y, [&](int b, int s) {
+            if (have_pend) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, s);     // previous row tile's Eterm, out-tile 4
+        });
+        RING_STAMP(P, 11);
+        if (tid == 0) s_next_tile[par] = claimed;
+        Prec::template layer_nb<2, AG_F, AG_NT, true, true, 2>(P, y, prev, noepi, to_x, [&](int b, int s) {
+            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);                        // first layer, out-tile 4
+        });
+        RING_STAMP(P, 13);
+        Prec::template layer_nb<2, AG_F, AG_NT, true, true, 0>(P, x, prev, noepi, to_y, [&](int b, int s) {
+            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_x, b, s);
+        });     // relation_encode
+        RING_STAMP(P, 14);
+        // phase 2: gather the next row tile's node rows (land under the last layer)
+        EdgeRaw g[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) edge_gather(a, nr[blk], ns[blk], g[blk]);
+        RING_STAMP(P, 15);
+        const EtermEpi epi[2] = {eterm_row(cur, 0), eterm_row(cur, 1)};
+        Prec::template layer_nb<2, AG_F, AG_NT, false, true, 2>(P, y, prev, epi, nosink, [&](int b, int s) {
+            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);
+        });
+        pend[0] = epi[0]; pend[1] = epi[1]; have_pend = true;
+        RING_STAMP(P, 16);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) edge_features(a, g[blk], h, in0[blk]);
+        RING_STAMP(P, 17);
+        cur = nxt;
+        nxt = s_next_tile[par];
+        par ^= 1;
+        RING_STAMP(P, 18);
+    }
+    if (have_pend) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, sh);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One propagation round at node level: fused segment reduce (aggregate_rows) or a pre-computed `agg` table,
 // then the node update (model.py:299-301), then either the next round's node-level relation terms (Hr, Hs)
 // or — after the last round — the decoder + clamp + integrate (model.py:306-309).
@@ -806,6 +1298,13 @@ void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
+    if (a.precision == AG_PREC_B3 && a.edge_rows == 64 && a.tile_ctr) {     // one 512-register workgroup per CU
+        const int tiles = (a.e_cap + AG_E64_ROWS - 1) / AG_E64_ROWS, slots = a.max_blocks / AG_MLP_WG_PER_CU;
+        const dim3 grid64(tiles < slots ? tiles : (slots > 0 ? slots : 1));
+        if (a.eterm_half) hipLaunchKernelGGL(edge_encode64_kernel<true>, grid64, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL(edge_encode64_kernel<false>, grid64, dim3(256), 0, s, w, a);
+        return;
+    }
     const dim3 grid(grid_for(a.e_cap, a.max_blocks)), block(AG_MLP_THREADS);
     if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(edge_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
     else hipLaunchKernelGGL(edge_encode_kernel<PrecF32>, grid, block, 0, s, w, a);

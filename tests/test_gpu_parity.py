@@ -229,6 +229,27 @@ def test_forward_repeatable_with_partial_last_tile(model):
         assert torch.equal(first, again)
 
 
+@pytest.mark.parametrize("precision", ["fast", "bf16x3"])
+def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, precision):
+    """The split-bf16 edge encoder that gives every wave two 32-edge blocks (one 512-register workgroup per CU, default)
+    keeps each row's MFMA accumulation chain: outputs are bit-identical to the 32-edges-per-wave kernel, on a batch whose
+    edge count leaves a partial 256-edge row tile, and are repeatable."""
+    m = make_model(weights, prec=precision)
+    g = synth.make_graph_inputs("rope", 700, 5, seed=11, spacing=0.1)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    assert int(csr.row_ptr[-1].item()) % 256 not in (0, 128)
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
+    m.set_option("edge_rows", 32)
+    _, m32 = m(*args, **kw)
+    m.set_option("edge_rows", 64)
+    _, m64 = m(*args, **kw)
+    assert torch.isfinite(m64).all() and torch.equal(m32, m64)
+    for _ in range(20):
+        _, again = m(*args, **kw)
+        assert torch.equal(m64, again)
+
+
 def test_forward_translation_invariance(model):
     """Positions enter only through differences (model.py:168-173 skipped, :250): shifting the cloud by a
     power-of-two offset (exact in fp32 at this magnitude) leaves pred_motion unchanged to rounding."""
