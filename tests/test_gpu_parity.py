@@ -231,9 +231,9 @@ def test_forward_repeatable_with_partial_last_tile(model):
 
 @pytest.mark.parametrize("precision", ["fast", "bf16x3"])
 def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, precision):
-    """The split-bf16 edge encoder that gives every wave two 32-edge blocks (one 512-register workgroup per CU, default)
-    keeps each row's MFMA accumulation chain: outputs are bit-identical to the 32-edges-per-wave kernel, on a batch whose
-    edge count leaves a partial 256-edge row tile, and are repeatable."""
+    """The optional split-bf16 edge encoder that gives every wave two 32-edge blocks (one 512-register workgroup per CU,
+    ag_set_option("edge_rows", 64)) keeps each row's MFMA accumulation chain: outputs are bit-identical to the default
+    32-edges-per-wave kernel, on a batch whose edge count leaves a partial 256-edge row tile, and are repeatable."""
     m = make_model(weights, prec=precision)
     g = synth.make_graph_inputs("rope", 700, 5, seed=11, spacing=0.1)
     csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
@@ -248,6 +248,7 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     for _ in range(20):
         _, again = m(*args, **kw)
         assert torch.equal(m64, again)
+    m.set_option("edge_rows", 32)
 
 
 def test_forward_translation_invariance(model):
