@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
         for (int i = 0; i < kFly; ++i) s[i] = sn[i];
     }
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + 4 * c) = acc;
+    if (a.status && !isfinite((acc.x + acc.y) + (acc.z + acc.w))) atomicOr(a.status, 1);
 }
 
 // Same reduction with Eterm stored as fp16 in accumulator order (precision mode 2: half the dominant HBM stream).
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     }
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0) = acc0;
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
+    // An fp16 Eterm entry beyond +-65504 was stored as inf (edge_encode, precision mode 2) and surfaces here as a
+    // non-finite sum: raise the model's sticky status bit (read by ag_model_status) instead of passing it on silently —
+    // the decoder's clamp (model.py:309) would otherwise turn it into a plausible +-100 motion.
+    if (a.status && !isfinite(((acc0.x + acc0.y) + (acc0.z + acc0.w)) + ((acc1.x + acc1.y) + (acc1.z + acc1.w)))) atomicOr(a.status, 1);
 }
 
 }  // namespace

@@ -3,6 +3,7 @@
 #include "../../include/adaptigraph_hip.h"
 #include "ag_common.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -135,6 +136,7 @@ struct ag_model {
     int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3|fast / ag_set_option("precision", 0|1|2)
     int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
+    double eterm_row_l1 = 0.0;  // max_o sum_k |W_rp[o, k]|, k < nf (bound used by the fp16 Eterm guard)
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
@@ -145,6 +147,7 @@ struct ag_model {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
     size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
     unsigned long long *edge_counter = nullptr;
+    int *status = nullptr;      // device word, sticky: bit 0 = non-finite message sum (fp16 Eterm overflow or non-finite inputs)
 };
 
 namespace {
@@ -182,8 +185,24 @@ int pack_and_upload(ag_model *m, const float *const *t)
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
+    } else {
+        // Re-packing a LIVE model: kernels still running on any stream (torch side streams are non-blocking, so the
+        // null-stream copy below is not ordered against them) may be reading the old streams.  Weight updates are rare
+        // (once per checkpoint / optimiser step evaluated through the engine): drain the device first.
+        AG_HIP(hipDeviceSynchronize());
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
+    // fp16 Eterm table (precision mode 2): |Eterm| <= ||W_e row||_1 * max|enc_e| + |b|.  The table saturates at 65504;
+    // record a conservative row-norm bound so that mode 2 can be refused for checkpoints whose per-edge term could overflow.
+    {
+        double worst = 0.0;
+        for (int o = 0; o < F; ++o) {
+            double l1 = 0.0;
+            for (int k = 0; k < F; ++k) l1 += fabs((double)t[W_RP][(size_t)o * 3 * F + k]);
+            worst = l1 > worst ? l1 : worst;
+        }
+        m->eterm_row_l1 = worst;
+    }
     auto at = [&](int b3, int k) { return reinterpret_cast<const float4 *>(m->dev + off[b3][k]); };
     m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
     m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
@@ -255,14 +274,15 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
     ~Timed() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
+void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
     a.fuse_agg = m->fuse_agg;
     a.precision = m->precision;
     a.eterm_half = m->eterm_half;
-    a.max_blocks = m->max_blocks;
+    a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
     a.edge_rows = m->edge_rows;
+    a.status = m->status;
     if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
@@ -280,7 +300,7 @@ void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
 
 void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
-    run_encode(m, a, s);
+    run_encode(m, a, s, m->max_blocks);
     run_propagate(m, a, s);
 }
 
@@ -322,8 +342,12 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
             m->max_blocks = AG_MLP_WG_PER_CU * prop.multiProcessorCount;
         if (const char *v = getenv("AG_MAX_BLOCKS")) m->max_blocks = atoi(v);
     }
-    const int rc = pack_and_upload(m, weights);
+    int rc = pack_and_upload(m, weights);
+    if (rc == AG_OK && (hipMalloc(reinterpret_cast<void **>(&m->status), sizeof(int)) != hipSuccess ||
+                        hipMemset(m->status, 0, sizeof(int)) != hipSuccess))
+        rc = fail(AG_ERR_HIP, "ag_model_create: status word allocation failed");
     if (rc != AG_OK) {
+        if (m->status) (void)hipFree(m->status);
         if (m->dev) (void)hipFree(m->dev);
         delete m;
         return rc;
@@ -349,6 +373,7 @@ int ag_model_destroy(ag_model *m)
         if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->status) (void)hipFree(m->status);
     if (m->dev) (void)hipFree(m->dev);
     delete m;
     return AG_OK;
@@ -425,6 +450,16 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else if (!strcmp(name, "edge_rows")) m->edge_rows = value == 32 ? 32 : 64;
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
+    return AG_OK;
+}
+
+int ag_model_status(ag_model *m, int *flags, ag_stream_t stream)
+{
+    if (!m || !flags) return fail(AG_ERR_ARG, "ag_model_status: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    AG_HIP(hipMemcpyAsync(flags, m->status, sizeof(int), hipMemcpyDeviceToHost, s));
+    AG_HIP(hipMemsetAsync(m->status, 0, sizeof(int), s));
+    AG_HIP(hipStreamSynchronize(s));
     return AG_OK;
 }
 
@@ -617,8 +652,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         for (int k = 1; k < parts; ++k) AG_HIP(hipStreamWaitEvent(m->aux_stream[k], m->ev_fork, 0));
     }
     const size_t plane = (size_t)N * 3;
-    const int saved_blocks = m->max_blocks;
-    m->max_blocks = saved_blocks / parts > 0 ? saved_blocks / parts : 1;
+    const int part_blocks = m->max_blocks / parts > 0 ? m->max_blocks / parts : 1;   // each part's persistent kernels take an equal share
     int rc = AG_OK;
     // issue the steps round-robin over the parts so every stream always has work queued
     struct Run { AgStepArgs st{}; hipStream_t s; } run[AG_MAX_PARTS];
@@ -648,15 +682,17 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         st.height_mode = p->height_mode; st.raise = p->gripper_raise;
     }
     for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
-        for (int k = 0; k < parts; ++k) {
+        for (int k = 0; k < parts && rc == AG_OK; ++k) {
             hipStream_t s = run[k].s;
             { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
-            run_encode(m, part[k].f, s);
+            run_encode(m, part[k].f, s, part_blocks);
             if (ai == 1 && k == 0 && parts > 1 && m->stagger) {
                 // phase offset: the other parts start once part 0 has finished its first MFMA-bound encode stage, so
                 // from then on one stream's HBM-bound segment reduce co-runs with another stream's MFMA-bound stage
-                AG_HIP(hipEventRecord(m->ev_fork, s0));
-                for (int kk = 1; kk < parts; ++kk) AG_HIP(hipStreamWaitEvent(m->aux_stream[kk], m->ev_fork, 0));
+                if (hipEventRecord(m->ev_fork, s0) != hipSuccess) { rc = AG_ERR_HIP; break; }
+                for (int kk = 1; kk < parts; ++kk)
+                    if (hipStreamWaitEvent(m->aux_stream[kk], m->ev_fork, 0) != hipSuccess) rc = AG_ERR_HIP;
+                if (rc != AG_OK) break;
             }
             run_propagate(m, part[k].f, s);
             run[k].st.step = ai;
@@ -668,12 +704,11 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
                            hipMemcpyDeviceToDevice, run[k].s) != hipSuccess)
             rc = AG_ERR_HIP;
     }
-    m->max_blocks = saved_blocks;
-    for (int k = 1; k < parts; ++k) {
-        AG_HIP(hipEventRecord(m->ev_join[k], m->aux_stream[k]));
-        AG_HIP(hipStreamWaitEvent(s0, m->ev_join[k], 0));
-    }
-    if (rc != AG_OK) return fail(rc, "ag_rollout: hipMemcpyAsync failed");
+    // every exit path joins the auxiliary streams back into the caller's stream
+    for (int k = 1; k < parts; ++k)
+        if (hipEventRecord(m->ev_join[k], m->aux_stream[k]) != hipSuccess || hipStreamWaitEvent(s0, m->ev_join[k], 0) != hipSuccess)
+            rc = AG_ERR_HIP;
+    if (rc != AG_OK) return fail(rc, "ag_rollout: a HIP runtime call failed: %s", hipGetErrorString(hipGetLastError()));
     AG_HIP(hipGetLastError());
     return AG_OK;
 }

@@ -199,15 +199,23 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
         }
         float cs = sqrtf(a.thr_sq[b]) * 1.002f;
         if (!(cs > 1e-20f)) cs = 1e-20f;
-        int nx, ny, nz;
-        for (;;) {   // coarsen until the grid fits the LDS histogram (larger cells stay exact, only less selective)
+        int nx = 1, ny = 1, nz = 1;
+        // coarsen until the grid fits the LDS histogram (larger cells stay exact, only less selective).  Non-finite
+        // extents (an Inf coordinate of a diverged rollout; NaNs never enter the min/max) or a cell size that overflows
+        // fall back to ONE cell: every valid particle is then a candidate of every receiver and the pair test itself
+        // decides, exactly like the reference, which yields no edge for a NaN/Inf distance (graph.py:121: `dis < thresh`).
+        bool ok = true;
+        for (int c = 0; c < 3; ++c) ok = ok && isfinite(mn[c]) && isfinite(mx[c]) && isfinite(mx[c] - mn[c]);
+        for (int it = 0; ok; ++it) {
             const float fx = (mx[0] - mn[0]) / cs, fy = (mx[1] - mn[1]) / cs, fz = (mx[2] - mn[2]) / cs;
             if (fx < 8000.f && fy < 8000.f && fz < 8000.f) {
                 nx = (int)fx + 1; ny = (int)fy + 1; nz = (int)fz + 1;
                 if ((long long)nx * ny * nz <= kCellMax) break;
             }
             cs *= 2.0f;
+            if (it > 300 || !isfinite(cs)) ok = false;
         }
+        if (!ok) { nx = ny = nz = 1; cs = 1.0f; for (int c = 0; c < 3; ++c) if (!isfinite(mn[c])) mn[c] = 0.f; }
         G.x0 = mn[0]; G.y0 = mn[1]; G.z0 = mn[2]; G.inv = 1.0f / cs; G.nx = nx; G.ny = ny; G.nz = nz; G.total = 0;
     }
     __syncthreads();

@@ -118,6 +118,7 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     phys = _physics(ppm_optimizer, physics_param, bsz, device)
     thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
     max_steps = repeat.max(dim=0).values.tolist()     # ONE host sync per call (reference: one per look-ahead + 3 per step)
+    model.take_status(device)                         # deferred numeric status of the previous calls (rides on that sync)
 
     seq = torch.zeros((bsz, n_look, n_obj, 3), device=device)
     obj = state[None].expand(bsz, n_obj, 3)
@@ -170,6 +171,7 @@ def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer
     phys = _physics(ppm_optimizer, physics_param, bsz, device)
     thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
     n_steps = int(repeat.max().item())
+    model.take_status(device)
     seq = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, repeat, n_steps, task["topk"],
                   task["connect_tools_all"], n_t, _lib.AG_HEIGHT_MASKED_MEAN, state_mask.bool(), raise_by)
     return {"state_seqs": seq, "action_seqs": decoded}

@@ -16,8 +16,9 @@ _WS = {}
 
 
 def workspace(device, nbytes):
-    """Grow-only per-device scratch buffer handed to the C ABI (the library never allocates scratch)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer handed to the C ABI (the library never allocates scratch), one per (device, stream):
+    calls enqueued on different streams may overlap, so they must not share scratch."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

@@ -7,6 +7,7 @@ returning `(pred_pos, pred_motion)`, same 22-tensor `state_dict()` layout, so
 libadaptigraph_hip.so.  Inference only (the north-star path has no backward).
 """
 import ctypes
+import warnings
 
 import torch
 import torch.nn as nn
@@ -116,9 +117,25 @@ class DynamicsPredictor(nn.Module):
             self._sync_weights()
         return self._handle
 
+    def take_status(self, device=None):
+        """Read-and-clear the model's sticky numeric status (ag_model_status; synchronises the current stream).
+        Bit 0: a non-finite message sum was produced — with finite inputs, an fp16 overflow of the per-edge table in
+        precision mode 2; warns once per occurrence and returns the flag word."""
+        dev = torch.device(device if device is not None else self.device)
+        flags = ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ag_model_status(self.handle(dev), ctypes.byref(flags), _stream_ptr(dev)), "ag_model_status")
+        if flags.value & 1:
+            warnings.warn("adaptigraph_amd: a forward produced non-finite message sums. If the inputs were finite, the fp16 "
+                          "per-edge table of precision mode 2 ('fast') overflowed (|Eterm| > 65504): use "
+                          "model.set_option('precision', 1).", RuntimeWarning, stacklevel=2)
+        return flags.value
+
     def set_option(self, name, value, device=None):
-        """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16
-        (default); "rollout_streams"; "fuse_aggregate"; "max_blocks"."""
+        """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16 with an
+        fp32 per-edge table, 2 = split-bf16 with the per-edge table stored as fp16 ("fast", the default: all three pass the
+        1e-4 gate on the reference forwards; 2 can overflow for |Eterm| > 65504, see take_status); "rollout_streams";
+        "fuse_aggregate"; "max_blocks"; "edge_rows"."""
         dev = torch.device(device if device is not None else self.device)
         _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
         return self

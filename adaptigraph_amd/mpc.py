@@ -10,7 +10,7 @@ import functools
 import torch
 
 from . import losses
-from .dist import dynamics_sharded
+from .dist import dynamics_sharded, replicate
 from .forward_dynamics import dynamics
 from .plan_utils import clip_actions, optimize_action_mppi, sample_action_seq
 
@@ -45,9 +45,12 @@ class MPPIPlanner:
         self.evaluate_traj = functools.partial(running_cost, error_func=error_func, penalty_func=penalty_func, bbox=bbox)
 
     def sample(self, act_seq, iter_index, device=None):
+        """Sampled action sequences, REPLICATED across the process group: every rank scores the gathered rollouts of all
+        samples against this tensor, so rank 0's draw is broadcast (ranks need not share an RNG state)."""
         dev = self.device if device is None else device
-        return sample_action_seq(act_seq.to(dev), self.lo.to(dev), self.hi.to(dev), self.n_sample, dev, iter_index=iter_index,
+        acts = sample_action_seq(act_seq.to(dev), self.lo.to(dev), self.hi.to(dev), self.n_sample, dev, iter_index=iter_index,
                                  noise_level=self.noise_level, push_length=self.push_length).to(self.device)
+        return replicate(acts)
 
     @torch.no_grad()
     def step(self, state_cur, act_seqs):

@@ -85,14 +85,20 @@ class _MessageSum(torch.autograd.Function):
 
 def gather_receivers(x, views):
     """x (M,D) -> (E,D) rows of each edge's receiver."""
+    if views.E == 0:
+        return x[:0] * 1.0
     return _GatherRows.apply(x, views.recv, views.row_ptr, None)
 
 
 def gather_senders(x, views):
     """x (M,D) -> (E,D) rows of each edge's sender."""
+    if views.E == 0:
+        return x[:0] * 1.0
     return _GatherRows.apply(x, views.send, views.col_ptr, views.send_perm)
 
 
 def message_sum(eterm, hr, hs, views):
     """(E,D), (M,D), (M,D) -> (M,D): sum over each receiver's edges of relu(eterm[e] + hr[recv] + hs[send])."""
+    if views.E == 0:      # a batch without edges (the reference's dense bmm handles it: model.py:295 on an empty Rr)
+        return hr.sum() * 0 + hs.sum() * 0 + torch.zeros_like(hr)
     return _MessageSum.apply(eterm, hr, hs, views)

@@ -10,12 +10,23 @@ One "step" = one pass of the hot path over one batch: `dynamics()` on `--batch` 
 "rope, ~1k particles, batch 256, 10-step rollout": per model step a radius-graph rebuild, the GNN forward and
 the state/tool update for every graph.  Multi-GPU: the batch shards across ranks with no data-path collective
 (weak scaling: per-GPU batch fixed), then ONE RCCL all-gather of the predicted states (north_star).
-Prints one JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
-kernel (edge_encode_kernel, fp32 MFMA bound) timed live with HIP events on the launch stream, and
-`cpu_baseline` = the CPU oracle ("port") timed on a bounded sample of the same workload on this box's cores.
+
+Prints one JSON line on rank 0 (contract in the task statement) with
+  roofline      edge_encode_kernel (MFMA-bound): achieved = F_min FLOP (140 100 per edge) x edges per
+                launch / average launch time, measured live with HIP events on the launch stream in a single-stream
+                pass, against the dense bf16 MFMA peak (split-bf16 modes) or the fp32 MFMA peak (f32 mode);
+                `mfma_issue_util` = the same with the 3 bf16 products per fp32 product the split modes issue;
+                `traffic` = HBM bytes per launch from the PMC passes recorded in profiles/pmc_traffic.json, used only
+                if that file was collected from the kernel sources being run (sha256 of adaptigraph_amd/csrc), else null
+  roofline_hbm  the segment-reduce kernel (HBM-bound), same accounting against 8 TB/s
+  cpu_baseline  the CPU oracle ("port") on a bounded sample of the same workload on this box's cores (N = 1 only)
+  extra         (N = 1 only) the exact-fp32 engine mode on the same workload, and BASELINE configs[2] / [3] per-GPU
+                shapes (granular-2k batch 128, cloth-4k batch 64 x 20 steps), each a short timed run of its own
+  ranks         (N > 1) per-rank rollout / all-gather milliseconds per step (min / max over ranks)
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -38,22 +49,43 @@ from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0                # HBM3E spec; 6290 GB/s is the measured float4-copy ceiling (same file)
-FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # edge encoder 17->150->150->150 + W_rp[:, :150] block
+FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # F_min edge work: encoder 17->150->150->150 + W_rp[:, :150] block
 PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
-# measured HBM traffic per launch, bytes (KB counters x 1024): edge_encode 2 x 27 176 KB read + 782 653 KB written;
-# aggregate_half 2 x 555 526 KB read + 160 160 KB written
-PMC_TRAFFIC = {("rope", 256, "fast", "edge_encode"): (2 * 27175.8 + 782652.8) * 1024,
-               ("rope", 256, "fast", "aggregate"): (2 * 555526.0 + 160160.4) * 1024}
 DTYPE = {"f32": "f32 (exact fp32 MFMA)",
          "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
          "fast": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate; per-edge table stored f16"}
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
-def cpu_baseline(weights, material, n_obj, kw, rollout_steps, seconds_budget=20.0):
+def csrc_sha():
+    """sha256 over the kernel sources (the GPU box has no .git: hash the files themselves)."""
+    d = os.path.join(ROOT, "adaptigraph_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(material, batch, precision, kernel):
+    """HBM bytes per launch (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, tools/pmc_traffic.py) or None when the
+    recorded passes were not collected from the sources being run."""
+    try:
+        rec = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json absent"
+    if rec.get("csrc_sha256") != csrc_sha():
+        return None, "profiles/pmc_traffic.json is stale (collected from other kernel sources)"
+    v = rec.get("entries", {}).get(f"{material}/{batch}/{precision}/{kernel}")
+    return (v, rec.get("source", "profiles/pmc_traffic.json")) if v is not None else (None, "workload not in profiles/pmc_traffic.json")
+
+
+def cpu_baseline(weights, material, n_obj, kw, seconds_budget=20.0):
     """Oracle ("port" of the reference algorithm: dense-formulation forward, O(N^2) edge build, per-step rebuild)
-    on a bounded sample: as many graphs as host threads, 2 rollout steps."""
+    on a bounded sample: as many graphs as host threads (<= 32), 2 rollout steps."""
     from oracle import ag_oracle as ago
     cores = os.cpu_count() or 1
     bsz = max(1, min(cores, 32))
@@ -74,6 +106,107 @@ def cpu_baseline(weights, material, n_obj, kw, rollout_steps, seconds_budget=20.
                       f"OpenMP over graphs, {cores} threads"}
 
 
+class Engine:
+    """One model + one workload on this rank's GPU; `run()` times `steps` passes of dynamics()."""
+
+    def __init__(self, material, weights, dev, world):
+        self.material, self.dev, self.world = material, dev, world
+        self.model = DynamicsPredictor(configs.model_config(), configs.material_config(material),
+                                       configs.dataset_config(material), dev)
+        self.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        self.model = self.model.to(dev).eval()
+        self.ppm = configs.ppm_optimizer_stub(material)
+        self.ppm.physics_param = {material: torch.tensor([0.5], device=dev)}
+        self.L = _lib.lib()
+        self.h = self.model.handle(torch.device(dev))
+
+    def opt(self, name, value):
+        _lib.check(self.L.ag_set_option(self.h, name.encode(), int(value)), f"ag_set_option({name})")
+
+    def sync(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, batch, T, precision, streams, steps, warmup, profile=True):
+        wl = WORKLOADS[self.material]
+        B_global = batch * self.world
+        state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
+        state = torch.from_numpy(state_np).to(self.dev)           # inputs resident in HBM before the timed region
+        action = torch.from_numpy(act_np).to(self.dev)
+        timing = {} if self.world > 1 else None
+
+        def one_pass(tm=None):
+            return agdist.dynamics_sharded(dynamics, state, action, self.model, self.dev, self.ppm, timing=tm)
+
+        self.opt("precision", PRECISIONS[precision])
+        self.opt("rollout_streams", streams)
+        for _ in range(warmup):
+            out = one_pass()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one_pass(timing)
+        self.sync()
+        dt = time.perf_counter() - t0
+        assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and bool(torch.isfinite(out["state_seqs"]).all())
+        res = {"B_global": B_global, "dt": dt, "ms_per_step": dt / steps * 1e3, "value": B_global * T * steps / dt,
+               "roofline": None, "roofline_hbm": None, "kernels": None}
+        if timing:
+            res["rank_ms"] = (agdist.elapsed_ms(timing["rollout"]) / steps, agdist.elapsed_ms(timing["gather"]) / steps)
+        if profile:
+            res.update(self.roofline_pass(one_pass, batch, precision, streams, min(3, max(1, steps))))
+        return res
+
+    def roofline_pass(self, one_pass, batch, precision, streams, n_prof):
+        """The same workload with the rollout on ONE stream (outside the timed region), so every kernel has the GPU to
+        itself and a launch duration means what a roofline needs it to mean; HIP events recorded by the library on the
+        launch stream around every launch (ag_profile_*)."""
+        L, h = self.L, self.h
+        self.opt("rollout_streams", 1)
+        one_pass()
+        _lib.check(L.ag_profile_enable(h, 1), "ag_profile_enable")
+        for _ in range(n_prof):
+            one_pass()
+        ms = (ctypes.c_double * 6)()
+        cnt = (ctypes.c_int64 * 6)()
+        edges = ctypes.c_int64()
+        _lib.check(L.ag_profile_read(h, ms, cnt, ctypes.byref(edges)), "ag_profile_read")
+        _lib.check(L.ag_profile_enable(h, 0), "ag_profile_enable")
+        self.opt("rollout_streams", streams)
+        kernels = {name: {"ms_per_launch": ms[i] / max(int(cnt[i]), 1), "launches": int(cnt[i])}
+                   for i, name in enumerate(_lib.KERNEL_CLASSES)}
+        roof = roof_hbm = None
+        k = _lib.KERNEL_CLASSES.index("edge_encode")
+        if cnt[k] > 0 and ms[k] > 0:
+            avg_s = ms[k] / cnt[k] * 1e-3
+            e_per = edges.value / cnt[k]
+            b3 = precision != "f32"
+            peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
+            achieved = FLOP_PER_EDGE * e_per / avg_s / 1e12           # algorithmic (F_min) FLOP only
+            traffic, src = pmc_traffic(self.material, batch, precision, "edge_encode")
+            roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
+                    "mfma_issue_util": (3 if b3 else 1) * achieved / peak,
+                    "algorithmic_bytes": e_per * ((320 if precision == "fast" else 640) + 68),
+                    "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": FLOP_PER_EDGE,
+                    "mfma": "v_mfma_f32_32x32x16_bf16, 3 per fp32 product (hi*hi + hi*lo + lo*hi)" if b3 else "v_mfma_f32_32x32x2_f32",
+                    "measured": f"HIP events on the launch stream, {n_prof} single-stream passes after the timed region"}
+            ka = _lib.KERNEL_CLASSES.index("aggregate")
+            if cnt[ka] > 0 and ms[ka] > 0:
+                # segment reduce: Eterm streamed once (640 B/edge fp32, 320 B f16), Hs rows gathered (first touch from
+                # HBM once per node, then L2), Hr read + agg written per node (SURVEY §8d B_alg terms)
+                n_nodes = batch * (WORKLOADS[self.material]["n_obj"] + synth.MATERIALS[self.material]["n_tools"])
+                nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * 3 * 640
+                a_s = ms[ka] / cnt[ka] * 1e-3
+                t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
+                roof_hbm = {"bound": "hbm", "kernel": "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
+                            "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS, "traffic": t2, "traffic_source": src2,
+                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes}
+        return {"roofline": roof, "roofline_hbm": roof_hbm, "kernels": kernels}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +217,7 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event roofline pass")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (f32 mode, granular-2k, cloth-4k)")
     ap.add_argument("--precision", default="fast", choices=sorted(PRECISIONS),
                     help="engine arithmetic mode; all three pass the 1e-4 parity gate (tests/test_gpu_parity.py)")
     ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
@@ -100,123 +234,64 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
 
-    wl = WORKLOADS[args.material]
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_seed0.npz")))
-    model = DynamicsPredictor(configs.model_config(), configs.material_config(args.material),
-                              configs.dataset_config(args.material), dev)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
-    model = model.to(dev).eval()
-    ppm = configs.ppm_optimizer_stub(args.material)
-    ppm.physics_param = {args.material: torch.tensor([0.5], device=dev)}
-
+    eng = Engine(args.material, weights, dev, world)
     T = args.rollout_steps
-    B_global = args.batch * world
-    state_np, act_np = synth.make_mpc_inputs(args.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9,
-                                             **wl["kw"])
-    state = torch.from_numpy(state_np).to(dev)           # inputs resident in HBM before the timed region
-    action = torch.from_numpy(act_np).to(dev)
+    r = eng.run(args.batch, T, args.precision, args.streams, args.steps, args.warmup, profile=not args.no_profile)
 
-    def one_pass():
-        return agdist.dynamics_sharded(dynamics, state, action, model, dev, ppm)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    L = _lib.lib()
-    h = model.handle(torch.device(dev))
-
-    def set_opt(name, value):
-        _lib.check(L.ag_set_option(h, name.encode(), int(value)), f"ag_set_option({name})")
-
-    set_opt("precision", PRECISIONS[args.precision])
-    set_opt("rollout_streams", args.streams)
-    for _ in range(args.warmup):
-        out = one_pass()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    sync()
-    dt = time.perf_counter() - t0
-    assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and bool(torch.isfinite(out["state_seqs"]).all())
-
-    # Roofline pass (outside the timed region): the same workload with the rollout on ONE stream, so every kernel
-    # has the GPU to itself and a launch duration means what a roofline needs it to mean (in the timed region two
-    # half-batch streams co-run and a kernel's wall time includes its neighbour's share of the CUs).
-    roof = None
-    kernels = None
-    if not args.no_profile:
-        set_opt("rollout_streams", 1)
-        one_pass()
-        _lib.check(L.ag_profile_enable(h, 1), "ag_profile_enable")
-        n_prof = max(1, min(3, args.steps))
-        for _ in range(n_prof):
-            one_pass()
-        ms = (ctypes.c_double * 6)()
-        cnt = (ctypes.c_int64 * 6)()
-        edges = ctypes.c_int64()
-        _lib.check(L.ag_profile_read(h, ms, cnt, ctypes.byref(edges)), "ag_profile_read")
-        _lib.check(L.ag_profile_enable(h, 0), "ag_profile_enable")
-        set_opt("rollout_streams", args.streams)
-        kernels = {name: {"ms_per_launch": ms[i] / max(int(cnt[i]), 1), "launches": int(cnt[i])}
-                   for i, name in enumerate(_lib.KERNEL_CLASSES)}
-        k = _lib.KERNEL_CLASSES.index("edge_encode")
-        roof_hbm = None
-        if cnt[k] > 0 and ms[k] > 0:
-            avg_s = ms[k] / cnt[k] * 1e-3
-            e_per = edges.value / cnt[k]
-            b3 = args.precision != "f32"
-            # algorithmic FLOP of the kernel's arithmetic: the split-bf16 modes need 3 bf16 products per fp32 product
-            flop_edge = FLOP_PER_EDGE * (3 if b3 else 1)
-            peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
-            achieved = flop_edge * e_per / avg_s / 1e12
-            # HBM bytes per launch from the PMC passes committed in profiles/r01_final_traffic_1stream.txt (FETCH_SIZE x 2
-            # per the gfx950 correction + WRITE_SIZE); only known for the default workload, null otherwise
-            traffic = PMC_TRAFFIC.get((args.material, args.batch, args.precision, "edge_encode"))
-            roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final_traffic_1stream.txt)",
-                    "algorithmic_bytes": e_per * ((320 if args.precision == "fast" else 640) + 68),
-                    "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": flop_edge,
-                    "fp32_equivalent_tflops": FLOP_PER_EDGE * e_per / avg_s / 1e12,
-                    "mfma": "v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi)" if b3 else "v_mfma_f32_32x32x2_f32",
-                    "measured": f"HIP events on the launch stream, {n_prof} single-stream passes after the timed region"}
-            ka = _lib.KERNEL_CLASSES.index("aggregate")
-            if cnt[ka] > 0 and ms[ka] > 0:
-                # segment reduce: Eterm streamed once (640 B/edge fp32, 320 B f16), Hs rows gathered (first touch from
-                # HBM once per node, then L2), Hr read + agg written per node (SURVEY §8d B_alg terms)
-                n_nodes = args.batch * (wl["n_obj"] + synth.MATERIALS[args.material]["n_tools"])
-                nbytes = e_per * (320 if args.precision == "fast" else 640) + n_nodes * 3 * 640
-                a_s = ms[ka] / cnt[ka] * 1e-3
-                roof_hbm = {"bound": "hbm", "kernel": "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS,
-                            "traffic": PMC_TRAFFIC.get((args.material, args.batch, args.precision, "aggregate")),
-                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes}
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([r["dt"]], dtype=torch.float64, device=dev)
+    ranks = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([r["ms_per_step"], r["rank_ms"][0], r["rank_ms"][1]], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        tab = torch.stack(allr).cpu().numpy()
+        ranks = {"ms_per_step": {"min": float(tab[:, 0].min()), "max": float(tab[:, 0].max())},
+                 "rollout_ms": {"min": float(tab[:, 1].min()), "max": float(tab[:, 1].max())},
+                 "all_gather_ms": {"min": float(tab[:, 2].min()), "max": float(tab[:, 2].max())},
+                 "note": "per step; rollout/all_gather from CUDA events around the local rollout and the collective"}
     dt = float(tmax.item())
 
+    extra = None
+    if world == 1 and not args.no_extra and args.material == "rope":
+        extra = {}
+        if args.precision != "f32":
+            e = eng.run(args.batch, T, "f32", args.streams, max(2, args.steps // 2), 1, profile=not args.no_profile)
+            extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"],
+                                 "arithmetic": DTYPE["f32"], "roofline": e["roofline"],
+                                 "note": "same workload, ag_set_option(precision, 0): the mode that matches every reference rollout golden"}
+        extra["workloads"] = {}
+        for mat, b, t, tag in (("granular", 128, 10, "BASELINE configs[2]"), ("cloth", 64, 20, "BASELINE configs[3], per-GPU share of batch 512 on 8 GPUs")):
+            e2 = Engine(mat, weights, dev, world)
+            x = e2.run(b, t, args.precision, args.streams, 3, 1, profile=not args.no_profile)
+            extra["workloads"][mat] = {"workload": f"{mat} {WORKLOADS[mat]['n_obj']} particles, batch {b}, {t}-step rollout ({tag})",
+                                       "value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"],
+                                       "precision": args.precision, "kernels": x["kernels"], "roofline": x["roofline"],
+                                       "roofline_hbm": x["roofline_hbm"]}
+            del e2
+
     if rank == 0:
+        wl = WORKLOADS[args.material]
         line = {
             "metric": "rollout graph-steps/s (batch x rollout steps / wall; edge build + GNN forward + state update per graph-step)",
-            "value": B_global * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
+            "value": r["B_global"] * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
             "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {args.batch}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
                                    f"{args.material} {wl['n_obj']} particles, batch {args.batch}/GPU, {T}-step rollout",
-                       "global_batch": B_global, "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather", "rollout_streams": args.streams,
-                       "weights": "seed-0 random init (reference default init)", "precision": args.precision,
-                       "arithmetic": DTYPE[args.precision]},
-            "roofline": roof, "roofline_hbm": roof_hbm if not args.no_profile else None, "kernels": kernels,
+                       "global_batch": r["B_global"], "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather",
+                       "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)",
+                       "precision": args.precision, "arithmetic": DTYPE[args.precision]},
+            "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }
+        if ranks:
+            line["ranks"] = ranks
+        if extra:
+            line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"], T)
+            line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"])
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:

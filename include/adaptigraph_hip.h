@@ -63,6 +63,13 @@ int ag_model_destroy(ag_model *m);
  *                            2 = mode 1 + the per-edge Eterm table stored as fp16 (2e-6..1.1e-5) (default 2) */
 int ag_set_option(ag_model *m, const char *name, int value);
 
+/* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on
+ * this model produced a non-finite message sum.  With finite inputs that is an overflow of the fp16 per-edge table of
+ * precision mode 2 (|Eterm| > 65504, possible with a trained checkpoint whose activations are large): switch the model
+ * to precision 1.  The reference has no counterpart (it computes in fp32 throughout, model.py:283-295). */
+enum { AG_STATUS_NONFINITE = 1 };
+int ag_model_status(ag_model *m, int *flags /*host*/, ag_stream_t stream);
+
 /* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */
 int64_t ag_edge_capacity(int B, int N, int topk, int connect_tools_all, int max_tools);
 size_t ag_edges_workspace_bytes(int B, int N, int topk, int connect_tools_all, int max_tools);

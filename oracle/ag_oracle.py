@@ -141,13 +141,18 @@ def _place_tool(task, decoded, theta, y):
 
 
 def _rollout_core(weights, task, states, delta, attrs, p_instance, phys, mask, tool_mask, radius, repeat, n_obj,
-                  height_fn, pstep):
-    """Inner loop shared by dynamics / dynamics_masked (forward_dynamics.py:156-197 / :351-393)."""
+                  height_fn, pstep, trace=None):
+    """Inner loop shared by dynamics / dynamics_masked (forward_dynamics.py:156-197 / :351-393).
+    `trace` (a list) receives, per model step, the inputs of that step: the state history and the edge lists built on
+    its newest frame (tests use it to teacher-force the engine along the reference trajectory)."""
     bsz = states.shape[0]
     out = np.zeros((bsz, n_obj, 3), np.float32)
     topk, connect = task["topk"], task["connect_tools_all"]
     n_rel, recv, send = build_edges(states[:, -1], radius, mask, tool_mask, topk, connect, "batch")
     for ai in range(1, 1 + int(repeat.max())):
+        if trace is not None:
+            trace.append(dict(states=states.copy(), delta=delta, attrs=attrs, p_instance=p_instance, phys=phys, mask=mask,
+                              tool_mask=tool_mask, radius=radius, n_rel=n_rel.copy(), recv=recv.copy(), send=send.copy()))
         pred, _ = forward(weights, states, attrs, delta, p_instance, phys, n_rel, recv, send, pstep=pstep)
         sel = repeat == ai
         out[sel] = pred[sel]
@@ -161,7 +166,7 @@ def _rollout_core(weights, task, states, delta, attrs, p_instance, phys, mask, t
     return out
 
 
-def dynamics(weights, task, state, action, radius=None, phys_value=0.5, pstep=3):
+def dynamics(weights, task, state, action, radius=None, phys_value=0.5, pstep=3, trace=None):
     """forward_dynamics.py:11-205.  state (n_obj,3), action (bsz,L,4) -> state_seqs (bsz,L,n_obj,3), action_seqs."""
     state, action = _f32(state), _f32(action)
     bsz, L = action.shape[:2]
@@ -192,7 +197,7 @@ def dynamics(weights, task, state, action, radius=None, phys_value=0.5, pstep=3)
         delta = np.zeros((bsz, N, 3), np.float32)
         delta[:, n_obj:] = delta_t
         seq[:, li] = _rollout_core(weights, task, states, delta, attrs, p_instance, phys, mask, tool_mask, radius,
-                                   repeat[:, li], n_obj, lambda pred: pred[:, :, 1].min(1), pstep)
+                                   repeat[:, li], n_obj, lambda pred: pred[:, :, 1].min(1), pstep, trace)
     return seq, decoded
 
 

@@ -105,12 +105,28 @@ def _gloo_worker(rank, world, port, total, q):
         out = agdist.dynamics_sharded(fake_dynamics, state, action, "x")
         full = fake_dynamics(state, action, "x")
         ok = all(torch.equal(out[k], full[k]) for k in full) and calls[0] <= (total + world - 1) // world
+        # a second call reuses the cached collective buffers; the first result must not be overwritten (copy semantics)
+        out2 = agdist.dynamics_sharded(fake_dynamics, state, action + 1.0, "x")
+        full2 = fake_dynamics(state, action + 1.0, "x")
+        ok = ok and all(torch.equal(out2[k], full2[k]) for k in full2) and all(torch.equal(out[k], full[k]) for k in full)
+        # replicated-input contract: per-rank draws differ until replicate() broadcasts rank 0's (MPPI samples)
+        torch.manual_seed(100 + rank)
+        draw = torch.rand(total, 2, 4)
+        try:
+            agdist.assert_replicated(draw, "draw")
+            ok = False
+        except RuntimeError:
+            pass
+        draw = agdist.replicate(draw)
+        agdist.assert_replicated(draw, "draw")
+        torch.manual_seed(100)
+        ok = ok and torch.equal(draw, torch.rand(total, 2, 4))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 5])
+@pytest.mark.parametrize("total", [8, 5, 1])
 def test_dynamics_sharded_gloo_world2(total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -7,7 +7,7 @@ for r in 32 64; do
   AG_EDGE_ROWS=$r python tools/time_forward.py 1 20 2>&1 | tail -1
 done
 for r in 32 64; do
-  AG_EDGE_ROWS=$r python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/ab_bench_$r.json 2> gpurun_out/ab_bench_$r.err
+  AG_EDGE_ROWS=$r python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/ab_bench_$r.json 2> gpurun_out/ab_bench_$r.err
   python - <<PY
 import json
 d = json.loads(open("gpurun_out/ab_bench_$r.json").read().strip().splitlines()[-1])
