@@ -441,6 +441,62 @@ int ag_message_backward(const float *eterm, const float *hr, const float *hs, co
     return AG_OK;
 }
 
+int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact, int n_tiles,
+                  float *dst, ag_stream_t stream)
+{
+    if (!W || !dst) return fail(AG_ERR_ARG, "ag_train_pack: null argument");
+    if (n_out < 1 || n_in < 1 || n_in > AG_F || ld < 1 || col0 < 0 || n_tiles < 1 || n_tiles > AG_NT || n_out > 32 * n_tiles * (compact ? AG_NT : 1))
+        return fail(AG_ERR_ARG, "ag_train_pack: bad sizes n_out=%d n_in=%d ld=%d n_tiles=%d", n_out, n_in, ld, n_tiles);
+    if (compact && n_in + (bias ? 1 : 0) > 32) return fail(AG_ERR_ARG, "ag_train_pack: compact image holds <= 32 input columns");
+    ag_launch_train_pack(W, bias, n_out, n_in, ld, col0, transposed ? 1 : 0, compact ? 1 : 0, n_tiles, dst, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_train_chain(int kind, int backward, const float *x, const float *packed, float *const *y, const float *dy, float *const *dz,
+                   float *dx, int64_t rows, int d_in, ag_stream_t stream)
+{
+    if (kind < AG_CHAIN_EDGE || kind > AG_CHAIN_DECODER) return fail(AG_ERR_ARG, "ag_train_chain: bad kind %d", kind);
+    const int L = kind == AG_CHAIN_EDGE ? 4 : 3;
+    if (!packed || !y || rows < 0 || (!backward && !x) || (backward && (!dy || !dz))) return fail(AG_ERR_ARG, "ag_train_chain: null argument");
+    if ((kind == AG_CHAIN_EDGE && d_in != AG_EDGE_IN) || (kind == AG_CHAIN_NODE && (d_in < 1 || d_in >= AG_NODE_IN_MAX)) ||
+        (kind == AG_CHAIN_DECODER && d_in != AG_F))
+        return fail(AG_ERR_ARG, "ag_train_chain: d_in=%d does not fit kind %d", d_in, kind);
+    AgChainArgsPOD p{};
+    p.x = x; p.w = packed; p.dy = dy; p.dx = dx; p.rows = rows; p.d_in = d_in;
+    for (int l = 0; l < L; ++l) {
+        if (!y[l] || (backward && !dz[l])) return fail(AG_ERR_ARG, "ag_train_chain: table %d is null", l);
+        p.y[l] = y[l];
+        p.dz[l] = backward ? dz[l] : nullptr;
+    }
+    if (rows == 0) return AG_OK;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    ag_launch_chain(kind, backward ? 1 : 0, p, AG_MLP_WG_PER_CU * cus, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers)
+{
+    return ag_weight_grads_ws_floats(rows, n_layers < 1 ? 1 : n_layers) * sizeof(float);
+}
+
+int ag_train_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
+                          int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream)
+{
+    if (n_layers < 1 || n_layers > 4 || !dz || !prev || !prev_ld || !n_in || !out || rows < 0) return fail(AG_ERR_ARG, "ag_train_weight_grads: bad argument");
+    for (int l = 0; l < n_layers; ++l)
+        if (!dz[l] || !prev[l] || n_in[l] < 1 || n_in[l] > AG_F || prev_ld[l] < n_in[l])
+            return fail(AG_ERR_ARG, "ag_train_weight_grads: layer %d: null table or n_in=%d ld=%d", l, n_in[l], prev_ld[l]);
+    if (!workspace || workspace_bytes < ag_train_weight_grads_workspace_bytes(rows, n_layers))
+        return fail(AG_ERR_WS, "ag_train_weight_grads: workspace %zu < %zu bytes", workspace_bytes, ag_train_weight_grads_workspace_bytes(rows, n_layers));
+    ag_launch_weight_grads(n_layers, dz, prev, prev_ld, n_in, rows, static_cast<float *>(workspace), out, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_set_option(ag_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");

@@ -122,5 +122,13 @@ void ag_launch_message_fwd(const float *eterm, const float *hr, const float *hs,
                            long long N, int D, hipStream_t s);
 void ag_launch_message_bwd(const float *eterm, const float *hr, const float *hs, const int *row_ptr, const int *send,
                            const float *g_agg, float *g_e, float *g_hr, long long N, int D, hipStream_t s);
+// training chains (ag_mlp.hip): kind 0 = relation_encoder + W_rp[:, :F], 1 = particle_encoder, 2 = non_rigid_predictor
+struct AgChainArgsPOD { const float *x; const float *w; float *y[4]; const float *dy; float *dz[4]; float *dx; long long rows; int d_in; };
+void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact,
+                          int n_tiles, float *dst, hipStream_t s);
+void ag_launch_chain(int kind, int backward, const AgChainArgsPOD &p, int max_blocks, hipStream_t s);
+size_t ag_weight_grads_ws_floats(long long rows, int n_layers);
+void ag_launch_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int *prev_ld, const int *n_in,
+                            long long rows, float *partial, float *out, hipStream_t s);
 int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
                       int y_batched, float *out, hipStream_t s);

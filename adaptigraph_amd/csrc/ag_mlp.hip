@@ -1273,6 +1273,175 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
     }
 }
 
+// =====================================================================================================
+// Training path: the dense stacks of DynamicsPredictor.forward and their backward on the
+// same fused-layer machinery, exact fp32 MFMA (PrecF32: gradients have to match the reference's fp32 autograd).
+//   forward  y_l = act_l(W_l y_{l-1} + b_l), l = 0..L-1, every y_l stored (row-major [rows][160]) for the backward
+//   backward dz_l = dy_l (.) [y_l > 0] (ReLU layers), dy_{l-1} = dz_l W_l — again a chain of fused layers, with the
+//            TRANSPOSED weights as the MFMA A operand and the ReLU mask applied in registers from the saved y_{l-1};
+//            every dz_l is stored: dW_l = dz_l^T y_{l-1} and db_l = sum_rows dz_l are plain library GEMMs / reductions
+//            over those tables (torch.mm in adaptigraph_amd/train_ops.py).
+// Replaces the F.linear chains of train.py:90-112's forward/backward for relation_encoder + W_rp[:, :F] (KIND_EDGE),
+// particle_encoder (KIND_NODE) and non_rigid_predictor (KIND_DEC); the activations never leave registers between
+// layers in either direction.
+// =====================================================================================================
+template <int KIND> struct ChainShape;
+template <> struct ChainShape<0> { static constexpr int L = 4, KF = AG_EDGE_IN + 1, RELU = 0x7; static constexpr bool NARROW = true; };   // RE0 RE1 RE2 We
+template <> struct ChainShape<1> { static constexpr int L = 3, KF = AG_NODE_IN_MAX, RELU = 0x7; static constexpr bool NARROW = true; };   // PE0 PE1 PE2
+template <> struct ChainShape<2> { static constexpr int L = 3, KF = 0, RELU = 0x3; static constexpr bool NARROW = false; };              // D0 D1 D2
+
+struct AgChainArgs {
+    const float *x;          // forward input: [rows][d_in] dense (narrow kinds) or [rows][160] (KIND_DEC)
+    const float4 *w;         // packed fp32 chunk stream (ag_train_pack): forward order, or transposed in backward order
+    float *y[4];             // per-layer outputs, row-major [rows_pad][160] (forward: written; backward: read)
+    const float *dy;         // backward: gradient w.r.t. y[L-1], [rows_pad][160]
+    float *dz[4];            // backward: per-layer pre-activation gradients, [rows_pad][160] (written)
+    float *dx;               // backward: gradient w.r.t. x, same shape as x (written), may be null
+    long long rows;
+    int d_in;
+};
+
+struct MaskStore {   // sink of a backward layer: dz = dy (.) [y > 0] (if MASK), stored row-major and handed on
+    const float *yrow; float *dzrow; bool mask;
+    __device__ __forceinline__ f32x16 operator()(int ti, const f32x16 &v) const
+    {
+        f32x16 r = v;
+        if (mask) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 y = *reinterpret_cast<const float4 *>(yrow + 32 * ti + 8 * q);
+                r[4 * q] = y.x > 0.f ? r[4 * q] : 0.f; r[4 * q + 1] = y.y > 0.f ? r[4 * q + 1] : 0.f;
+                r[4 * q + 2] = y.z > 0.f ? r[4 * q + 2] : 0.f; r[4 * q + 3] = y.w > 0.f ? r[4 * q + 3] : 0.f;
+            }
+        }
+        RowStoreEpi{dzrow}(ti, r);
+        return r;
+    }
+};
+
+template <int KIND>
+__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void chain_forward_kernel(AgChainArgs a)
+{
+    typedef ChainShape<KIND> S;
+    typedef PrecF32 Prec;
+    AG_LDS_DECL
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const long long ntiles = (a.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
+    ChunkPipe P{a.w, (S::NARROW ? 1 : AG_NT) + AG_NT * (S::L - 1), 0, 0, lds};
+    pipe_start(P);
+    (void)s_next_tile;
+#pragma unroll 1
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long g = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
+        const long long gc = g < a.rows ? g : 0;
+        const size_t rowoff = (size_t)g * AG_FP + 4 * h;      // own row even past `rows` (tables are padded to whole row tiles)
+        typename Prec::Act x, y;
+        if constexpr (S::NARROW) {
+            f32x16 in0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in0[r] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < (S::KF + 7) / 8; ++q)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int k = 8 * q + 4 * h + p;
+                    in0[4 * q + p] = k < a.d_in ? a.x[(size_t)gc * a.d_in + k] : (k == a.d_in ? 1.0f : 0.0f);   // bias column
+                }
+            Prec::set_tile(x, 0, in0);
+            Prec::template layer_first<S::KF>(P, x, [&](int ti, const f32x16 &v) { RowStoreEpi{a.y[0] + rowoff}(ti, v); Prec::set_tile(y, ti, v); });
+        } else {
+            f32x16 v[AG_NT];
+            load_rowmajor(a.x + (size_t)gc * AG_FP, v, h);
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, v[t]);
+            if constexpr (S::RELU & 1) dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, RowStoreEpi{a.y[0] + rowoff});
+            else dense<Prec, AG_F, false, true>(P, x, y, ZeroInit{}, RowStoreEpi{a.y[0] + rowoff});
+        }
+        static_for<1, S::L>([&](auto LI) {
+            constexpr int l = decltype(LI)::value;
+            auto &in = (l & 1) ? y : x;
+            auto &out = (l & 1) ? x : y;
+            if constexpr ((S::RELU >> l) & 1) dense<Prec, AG_F, true, true>(P, in, out, ZeroInit{}, RowStoreEpi{a.y[l] + rowoff});
+            else dense<Prec, AG_F, false, true>(P, in, out, ZeroInit{}, RowStoreEpi{a.y[l] + rowoff});
+        });
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void chain_backward_kernel(AgChainArgs a)
+{
+    typedef ChainShape<KIND> S;
+    typedef PrecF32 Prec;
+    AG_LDS_DECL
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const long long ntiles = (a.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
+    // transposed stream, in the order the backward consumes it: W_{L-1}^T ... W_1^T (5 chunks each), then W_0^T
+    // (one 32-row tile when the input is narrow, else 5)
+    ChunkPipe P{a.w, AG_NT * (S::L - 1) + (S::NARROW ? 1 : AG_NT), 0, 0, lds};
+    pipe_start(P);
+    (void)s_next_tile;
+#pragma unroll 1
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long g = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
+        const bool valid = g < a.rows;
+        const size_t rowoff = (size_t)g * AG_FP + 4 * h;
+        typename Prec::Act x, y;
+        {   // dz_{L-1} = dy (.) [y_{L-1} > 0]
+            f32x16 v[AG_NT];
+            load_rowmajor(a.dy + (size_t)g * AG_FP, v, h);
+            const MaskStore ms{a.y[S::L - 1] + rowoff, a.dz[S::L - 1] + rowoff, ((S::RELU >> (S::L - 1)) & 1) != 0};
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, ms(t, v[t]));
+        }
+        static_for<1, S::L>([&](auto LI) {           // dz_{l-1} = (dz_l W_l) (.) [y_{l-1} > 0],  l = L-1 .. 1
+            constexpr int l = S::L - decltype(LI)::value;       // L-1, L-2, ..., 1
+            constexpr bool odd = (S::L - 1 - l) & 1;
+            auto &in = odd ? y : x;
+            auto &out = odd ? x : y;
+            const MaskStore ms{a.y[l - 1] + rowoff, a.dz[l - 1] + rowoff, ((S::RELU >> (l - 1)) & 1) != 0};
+            Prec::template layer<AG_F, AG_NT, false, false>(P, in, ZeroInit{}, NoEpi{}, [&](int ti, const f32x16 &v) { Prec::set_tile(out, ti, ms(ti, v)); });
+        });
+        auto &last = ((S::L - 1) & 1) ? y : x;          // dz_0
+        if constexpr (S::NARROW) {                       // dx = dz_0 W_0: the d_in <= 24 input columns are rows 0.. of ONE out-tile
+            f32x16 m;
+            Prec::template layer<AG_F, 1, false, false>(P, last, ZeroInit{}, NoEpi{}, [&](int, const f32x16 &v) { m = v; });
+            if (a.dx && valid) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int k = 8 * q + 4 * h + p;
+                        if (k < a.d_in) a.dx[(size_t)g * a.d_in + k] = m[4 * q + p];
+                    }
+            }
+        } else {
+            dense_store<Prec, AG_F, false, false>(P, last, ZeroInit{}, RowStoreEpi{a.dx + rowoff});
+        }
+    }
+}
+
+// Device-side weight packing for the training chains (weights change every optimiser step, so the host-side packer of
+// ag_model_create is not an option): writes fp32 chunk images (layout: ag_common.h) of
+//   op(W)[o][k] = transposed ? W[k * ld + col0 + o] : W[o * ld + col0 + k],  o < n_out, k < n_in;  column n_in = bias[o]
+// `compact`: the one-chunk first-layer image [5 tiles][32 rows][32 floats]; else n_tiles standard images.
+__global__ __launch_bounds__(256) void train_pack_kernel(const float *W, const float *bias, int n_out, int n_in, int ld, int col0,
+                                                         int transposed, int compact, int n_tiles, float *dst)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int total = (compact ? 1 : n_tiles) * AG_CHUNK_FLOATS;
+    if (t >= total) return;
+    int tile, i, c;
+    if (compact) { tile = t / 1024; i = (t % 1024) / 32; c = t % 32; }
+    else { tile = t / AG_CHUNK_FLOATS; i = (t % AG_CHUNK_FLOATS) / AG_WSTRIDE; c = t % AG_WSTRIDE; }
+    const int k = 4 * ((c >> 2) ^ ((i >> 1) & 7)) + (c & 3), o = 32 * tile + i;
+    float v = 0.0f;
+    if (o < n_out) {
+        if (k < n_in) v = transposed ? W[(size_t)k * ld + col0 + o] : W[(size_t)o * ld + col0 + k];
+        else if (k == n_in && bias) v = bias[o];
+    }
+    dst[t] = v;
+}
+
 }  // namespace
 
 #if AG_TRACE
@@ -1320,4 +1489,24 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
         if (last) hipLaunchKernelGGL((node_update_kernel<PrecF32, true>), grid, block, 0, s, w, a);
         else hipLaunchKernelGGL((node_update_kernel<PrecF32, false>), grid, block, 0, s, w, a);
     }
+}
+
+void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact,
+                          int n_tiles, float *dst, hipStream_t s)
+{
+    const int total = (compact ? 1 : n_tiles) * AG_CHUNK_FLOATS;
+    hipLaunchKernelGGL(train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, bias, n_out, n_in, ld, col0, transposed, compact, n_tiles, dst);
+}
+
+void ag_launch_chain(int kind, int backward, const AgChainArgsPOD &p, int max_blocks, hipStream_t s)
+{
+    AgChainArgs a;
+    a.x = p.x; a.w = reinterpret_cast<const float4 *>(p.w); a.dy = p.dy; a.dx = p.dx; a.rows = p.rows; a.d_in = p.d_in;
+    for (int l = 0; l < 4; ++l) { a.y[l] = p.y[l]; a.dz[l] = p.dz[l]; }
+    const long long tiles = (p.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
+    const dim3 grid((unsigned)(tiles < max_blocks ? (tiles > 0 ? tiles : 1) : max_blocks)), block(AG_MLP_THREADS);
+#define AG_CHAIN_CASE(K) \
+    case K: if (backward) hipLaunchKernelGGL(chain_backward_kernel<K>, grid, block, 0, s, a); else hipLaunchKernelGGL(chain_forward_kernel<K>, grid, block, 0, s, a); break;
+    switch (kind) { AG_CHAIN_CASE(0) AG_CHAIN_CASE(1) AG_CHAIN_CASE(2) default: break; }
+#undef AG_CHAIN_CASE
 }

@@ -1,11 +1,11 @@
 // ag_train.hip — graph kernels of the TRAINING path: the gather / segment-reduce pieces of
-// DynamicsPredictor.forward (src/dynamics/gnn/model.py:220-295) and their adjoints, on the CSR adjacency.
+// DynamicsPredictor.forward (src/dynamics/gnn/model.py:220-295) and their adjoints, on the CSR adjacency, and the
+// weight-gradient reduction of the fused dense chains (the chains themselves: ag_mlp.hip).
 //
 // The reference trains with one-hot Rr/Rs `bmm`s, whose autograd is again dense bmm.  Here the forward gathers rows by
 // index and segment-reduces messages over receiver-sorted edges, and the backward is the transposed pair: gradients
 // w.r.t. gathered rows are segment sums over a (pointer, permutation) view of the same edges, so every reduction has
-// a fixed order — no atomics, bit-reproducible gradients.  Dense layers stay library GEMMs (torch / hipBLASLt) in this
-// path; only the inference path fuses them (ag_mlp.hip).  Feature width D is arbitrary (plain row-major torch tensors):
+// a fixed order — no atomics, bit-reproducible gradients.  Feature width D is arbitrary (plain row-major torch tensors):
 // one thread per (row, feature), consecutive threads on consecutive features, so every access is coalesced along D.
 #include "ag_common.h"
 
@@ -70,6 +70,78 @@ __global__ __launch_bounds__(256) void message_bwd_kernel(const float *eterm, co
     g_hr[t] = acc;
 }
 
+// ---- weight gradients of the fused dense chains (ag_mlp.hip: chain_backward_kernel) ---------------------------------------
+// dW_l[o][k] = sum_rows dz_l[row][o] * prev_l[row][k]  and  db_l[o] = sum_rows dz_l[row][o]   (prev_l = input of layer l).
+// The shape defeats library GEMMs: a 150 x 150 output contracted over 10^4..10^5 rows has 25 output tiles, so hipBLASLt ran
+// it on 25 workgroups (88 us per layer, 4.2 of the 10.9 ms training step, profiles/r02_train_trace.txt).  Here the ROWS are split into
+// slabs, one workgroup per (slab, layer): five waves, wave w owns the 32-feature strip o in [32w, 32w+32) against all five
+// k-tiles, two rows per exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A = dz^T, B = prev; both read as 128-byte row segments), and
+// a second kernel adds the slab partials in ascending slab order: fixed summation order, bit-reproducible, no atomics.
+// The bias gradient rides along as one more k column: prev is read as 1.0 at column n_in.
+constexpr int kDwSlab = 256;            // rows per workgroup
+struct DwArgs {
+    const float *dz[4], *prev[4];
+    int prev_ld[4], n_in[4];
+    long long rows;
+    float *partial;                      // [n_slabs][n_layers][160][160]
+    float *out;                          // [n_layers][160][160]: out[l][o][k] = dW_l[o][k] (k < n_in), out[l][o][n_in] = db_l[o]
+    int n_slabs, n_layers;
+};
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
+{
+    const int slab = blockIdx.x, l = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const float *dz = a.dz[l], *pv = a.prev[l];
+    const int ld = a.prev_ld[l], n_in = a.n_in[l];
+    const int kt = (n_in + 1 + 31) / 32;                  // k-tiles that hold data (incl. the bias column)
+    f32x16_t acc[AG_NT];
+#pragma unroll
+    for (int t = 0; t < AG_NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const long long r0 = (long long)slab * kDwSlab;
+    const long long r1 = r0 + kDwSlab < a.rows ? r0 + kDwSlab : a.rows;
+    constexpr int U = 8;                                  // row pairs per iteration: all their loads are issued before the first MFMA
+    for (long long rb = r0; rb < r1; rb += 2 * U) {       // lane half h takes row rb + 2u + h (the MFMA's k index)
+        float av[U], bv[U][AG_NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rb + 2 * u + h;
+            const bool ok = r < r1;
+            av[u] = ok ? dz[(size_t)r * AG_FP + 32 * w + j] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t) {
+                const int k = 32 * t + j;
+                bv[u][t] = (ok && t < kt) ? (k < n_in ? pv[(size_t)r * ld + k] : (k == n_in ? 1.0f : 0.0f)) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t)
+                if (t < kt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    }
+    float *dst = a.partial + ((size_t)slab * a.n_layers + l) * AG_FP * AG_FP;
+#pragma unroll
+    for (int t = 0; t < AG_NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dst[(size_t)(32 * w + 8 * q + 4 * h + p) * AG_FP + 32 * t + j] = acc[t][4 * q + p];
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(DwArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (t >= AG_FP * AG_FP) return;
+    float s = 0.0f;
+    for (int slab = 0; slab < a.n_slabs; ++slab) s += a.partial[((size_t)slab * a.n_layers + l) * AG_FP * AG_FP + t];
+    a.out[(size_t)l * AG_FP * AG_FP + t] = s;
+}
+
 inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -92,4 +164,21 @@ void ag_launch_message_bwd(const float *eterm, const float *hr, const float *hs,
 {
     if (N * D > 0)
         hipLaunchKernelGGL(message_bwd_kernel, dim3(blocks_for(N * D)), dim3(256), 0, s, eterm, hr, hs, row_ptr, send, g_agg, g_e, g_hr, N * D, D);
+}
+
+size_t ag_weight_grads_ws_floats(long long rows, int n_layers)
+{
+    const long long slabs = (rows + kDwSlab - 1) / kDwSlab;
+    return (size_t)(slabs > 0 ? slabs : 1) * n_layers * AG_FP * AG_FP;
+}
+void ag_launch_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int *prev_ld, const int *n_in,
+                            long long rows, float *partial, float *out, hipStream_t s)
+{
+    DwArgs a{};
+    for (int l = 0; l < n_layers; ++l) { a.dz[l] = dz[l]; a.prev[l] = prev[l]; a.prev_ld[l] = prev_ld[l]; a.n_in[l] = n_in[l]; }
+    a.rows = rows; a.partial = partial; a.out = out; a.n_layers = n_layers;
+    a.n_slabs = (int)((rows + kDwSlab - 1) / kDwSlab);
+    if (a.n_slabs < 1) a.n_slabs = 1;
+    hipLaunchKernelGGL(dw_partial_kernel, dim3(a.n_slabs, n_layers), dim3(320), 0, s, a);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((AG_FP * AG_FP + 255) / 256, n_layers), dim3(256), 0, s, a);
 }

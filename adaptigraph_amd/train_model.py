@@ -2,9 +2,12 @@
 src/dynamics/train/train.py:66-130).
 
 Same parameters, state_dict and call signature as the inference `DynamicsPredictor` (a checkpoint trained here loads into
-the fused engine unchanged), but `forward` is built from autograd-capable pieces: library GEMMs (torch / hipBLASLt) for the
-dense layers and the HIP gather / segment-reduce kernels of `train_ops` on the CSR adjacency for the graph part — the
-reference's one-hot `bmm`s never exist.  The relation propagator runs in its column-split form
+the fused engine unchanged), but `forward` is built from autograd-capable pieces: the three Linear(+ReLU) stacks
+(relation_encoder + the edge block of relation_propagator, particle_encoder, non_rigid_predictor: > 95 % of the dense FLOPs)
+run forward AND backward as fused exact-fp32 MFMA chain kernels (`train_ops.fused_chain`: activations stay in registers
+between layers, weight gradients are one library GEMM per layer over the saved tables), the per-round node-level linears are
+library GEMMs (torch / hipBLASLt), and the graph part is the HIP gather / segment-reduce kernels of `train_ops` on the CSR
+adjacency — the reference's one-hot `bmm`s never exist.  The relation propagator runs in its column-split form
 (`W_rp = [W_e | W_r | W_s]`), which is the same function of the same 22 tensors, so autograd reaches the
 original `relation_propagator.linear.weight` through its three slices.
 """
@@ -13,7 +16,7 @@ import torch.nn.functional as F
 
 from .graph import CSREdges, csr_from_dense
 from .model import DynamicsPredictor
-from .train_ops import EdgeViews, gather_receivers, gather_senders, message_sum
+from .train_ops import EdgeViews, fused_chain, gather_receivers, gather_senders, message_sum
 
 
 def _mlp3(block, x):
@@ -23,6 +26,8 @@ def _mlp3(block, x):
 
 
 class TrainableDynamicsPredictor(DynamicsPredictor):
+    fused_dense = True     # encoder / decoder stacks on the fused MFMA chain kernels (False: library GEMMs, the r01 path)
+
     def forward(self, state, attrs, Rr, Rs, p_instance, action=None, particle_den=None, obj_mask=None, **kwargs):
         dev = state.device
         B, N = attrs.size(0), attrs.size(1)
@@ -48,20 +53,30 @@ class TrainableDynamicsPredictor(DynamicsPredictor):
         rel_inputs = torch.cat([tab_r[:, :a], tab_s[:, :a], (tab_r[:, a:a + g] - tab_s[:, a:a + g]).abs().sum(1, keepdim=True),
                                 tab_r[:, a + g:] - tab_s[:, a + g:]], 1)
 
-        enc_n = _mlp3(self.particle_encoder, p_inputs)                               # :268
-        enc_e = _mlp3(self.relation_encoder, rel_inputs)                             # :274
         w_rp, b_rp = self.relation_propagator.linear.weight, self.relation_propagator.linear.bias
         w_pp, b_pp = self.particle_propagator.linear.weight, self.particle_propagator.linear.bias
-        eterm = F.linear(enc_e, w_rp[:, :nf], b_rp)                                  # round-invariant edge term
+        if self.fused_dense:      # the three Linear(+ReLU) stacks on the fused MFMA chain kernels, forward and backward
+            pe, re = self.particle_encoder.model, self.relation_encoder.model
+            enc_n = fused_chain("node", p_inputs, [(pe[i].weight, pe[i].bias) for i in (0, 2, 4)])            # :268
+            eterm = fused_chain("edge", rel_inputs, [(re[i].weight, re[i].bias) for i in (0, 2, 4)] + [(w_rp[:, :nf], b_rp)]) \
+                if views.E else rel_inputs.new_zeros((0, nf))                                                 # :274, :289 first block
+        else:
+            enc_n = _mlp3(self.particle_encoder, p_inputs)                               # :268
+            enc_e = _mlp3(self.relation_encoder, rel_inputs)                             # :274
+            eterm = F.linear(enc_e, w_rp[:, :nf], b_rp)                                  # round-invariant edge term
         h = enc_n
         for _ in range(self.model_config["pstep"]):                                  # :283-301
             agg = message_sum(eterm, F.linear(h, w_rp[:, nf:2 * nf]), F.linear(h, w_rp[:, 2 * nf:]), views)
             h = F.relu(F.linear(torch.cat([enc_n, agg], 1), w_pp, b_pp) + h)
         d = self.non_rigid_predictor
         x = h.reshape(B, N, nf)[:, :n_p].reshape(B * n_p, nf)
-        x = F.relu(F.linear(x, d.linear_0.weight, d.linear_0.bias))
-        x = F.relu(F.linear(x, d.linear_1.weight, d.linear_1.bias))
-        pred_motion = F.linear(x, d.linear_2.weight, d.linear_2.bias).reshape(B, n_p, 3)
+        if self.fused_dense:
+            pred_motion = fused_chain("decoder", x, [(d.linear_0.weight, d.linear_0.bias), (d.linear_1.weight, d.linear_1.bias),
+                                                     (d.linear_2.weight, d.linear_2.bias)]).reshape(B, n_p, 3)
+        else:
+            x = F.relu(F.linear(x, d.linear_0.weight, d.linear_0.bias))
+            x = F.relu(F.linear(x, d.linear_1.weight, d.linear_1.bias))
+            pred_motion = F.linear(x, d.linear_2.weight, d.linear_2.bias).reshape(B, n_p, 3)
         pred_pos = state[:, -1, :n_p] + torch.clamp(pred_motion, max=self.motion_clamp, min=-self.motion_clamp)   # :309
         return pred_pos, pred_motion
 

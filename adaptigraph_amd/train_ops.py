@@ -4,10 +4,12 @@
 their backward passes are segment sums over a (pointer, permutation) view of the same edge list, so gradients are
 reproducible bit for bit (the reference's dense bmm autograd is too; index_add-style atomics would not be).
 """
+import ctypes
+
 import torch
 
 from . import _lib
-from .graph import CSREdges, _require_gpu, _stream_ptr
+from .graph import CSREdges, _require_gpu, _stream_ptr, workspace
 
 
 class EdgeViews:
@@ -102,3 +104,115 @@ def message_sum(eterm, hr, hs, views):
     if views.E == 0:      # a batch without edges (the reference's dense bmm handles it: model.py:295 on an empty Rr)
         return hr.sum() * 0 + hs.sum() * 0 + torch.zeros_like(hr)
     return _MessageSum.apply(eterm, hr, hs, views)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Dense stacks on the fused MFMA kernels (csrc/ag_mlp.hip: chain_forward_kernel / chain_backward_kernel)
+# ---------------------------------------------------------------------------------------------------------------------
+AG_FP, _ROW_TILE, _CHUNK = 160, 128, 5120
+CHAIN_KINDS = {"edge": (0, 4), "node": (1, 3), "decoder": (2, 3)}      # name -> (AG_CHAIN_*, layers)
+_PACK_CACHE = {}
+
+
+def _pack_chain(kind, layers, dev):
+    """Pack [(W, b)] into the forward stream and the transposed backward stream (device-side, one launch per layer), cached
+    until a parameter is updated in place (optimiser step) or replaced."""
+    key = (kind, dev.index) + tuple((W.data_ptr(), W._version, b.data_ptr(), b._version) for W, b in layers)
+    hit = _PACK_CACHE.get((kind, dev.index))
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    L = _lib.lib()
+    narrow = kind != "decoder"
+    n = len(layers)
+    fwd = torch.empty(((1 if narrow else 5) + 5 * (n - 1)) * _CHUNK, dtype=torch.float32, device=dev)
+    bwd = torch.empty((5 * (n - 1) + (1 if narrow else 5)) * _CHUNK, dtype=torch.float32, device=dev)
+    st = _stream_ptr(dev)
+    with torch.cuda.device(dev):
+        off = 0
+        for l, (W, b) in enumerate(layers):
+            n_out, n_in = W.shape
+            assert W.stride(1) == 1 and b.is_contiguous()
+            compact = narrow and l == 0
+            _lib.check(L.ag_train_pack(W.data_ptr(), b.data_ptr(), n_out, n_in, W.stride(0), 0, 0, int(compact), 1 if compact else 5,
+                                       fwd.data_ptr() + 4 * off, st), "ag_train_pack")
+            off += _CHUNK * (1 if compact else 5)
+        off = 0
+        for l in range(n - 1, -1, -1):
+            W, _ = layers[l]
+            n_out, n_in = W.shape
+            tiles = 1 if (narrow and l == 0) else 5
+            _lib.check(L.ag_train_pack(W.data_ptr(), None, n_in, n_out, W.stride(0), 0, 1, 0, tiles, bwd.data_ptr() + 4 * off, st), "ag_train_pack")
+            off += _CHUNK * tiles
+    _PACK_CACHE[(kind, dev.index)] = (key, fwd, bwd)
+    return fwd, bwd
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * 4)(*([t.data_ptr() for t in tensors] + [None] * (4 - len(tensors))))
+
+
+class _FusedChain(torch.autograd.Function):
+    """y = layer_{L-1}(... layer_0(x)) with the kind's fixed widths and ReLU pattern; saves every layer output, backward =
+    one fused kernel for the input / pre-activation gradients + one library GEMM and one column sum per layer."""
+
+    @staticmethod
+    def forward(ctx, kind, x, *params):
+        _require_gpu(x, "x")
+        code, n = CHAIN_KINDS[kind]
+        layers = [(params[2 * l], params[2 * l + 1]) for l in range(n)]
+        dev = x.device
+        rows = x.shape[0]
+        rows_pad = max(_ROW_TILE, -(-rows // _ROW_TILE) * _ROW_TILE)
+        fwd, bwd = _pack_chain(kind, [(W.detach(), b.detach()) for W, b in layers], dev)
+        if kind == "decoder":
+            xin = x.new_zeros((rows_pad, AG_FP))
+            xin[:rows, : x.shape[1]] = x
+        else:
+            xin = x.contiguous().float()
+        ys = [torch.empty((rows_pad, AG_FP), dtype=torch.float32, device=dev) for _ in range(n)]
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ag_train_chain(code, 0, xin.data_ptr(), fwd.data_ptr(), _ptr_array(ys), None, _ptr_array([]), None, rows,
+                                           x.shape[1], _stream_ptr(dev))
+        _lib.check(rc, "ag_train_chain(forward)")
+        ctx.kind, ctx.rows, ctx.d_in, ctx.bwd = kind, rows, x.shape[1], bwd
+        ctx.shapes = [tuple(W.shape) for W, _ in layers]
+        ctx.save_for_backward(xin, *ys)
+        return ys[-1][:rows, : layers[-1][0].shape[0]]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xin, *ys = ctx.saved_tensors
+        code, n = CHAIN_KINDS[ctx.kind]
+        dev, rows = xin.device, ctx.rows
+        rows_pad = ys[0].shape[0]
+        dy = torch.zeros((rows_pad, AG_FP), dtype=torch.float32, device=dev)
+        dy[:rows, : grad_out.shape[1]] = grad_out
+        dzs = [torch.empty((rows_pad, AG_FP), dtype=torch.float32, device=dev) for _ in range(n)]
+        dx = torch.empty_like(xin)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ag_train_chain(code, 1, xin.data_ptr(), ctx.bwd.data_ptr(), _ptr_array(ys), dy.data_ptr(), _ptr_array(dzs),
+                                           dx.data_ptr(), rows, ctx.d_in, _stream_ptr(dev))
+        _lib.check(rc, "ag_train_chain(backward)")
+        # dW_l = dz_l^T y_{l-1}, db_l = column sums of dz_l: all layers in two launches (row-slab split-K on the fp32 MFMA,
+        # fixed-order reduction) — a 150 x 150 output over 10^4..10^5 rows runs on 25 workgroups as a library GEMM
+        prevs = [xin] + ys[:-1]
+        n_ins = [s[1] for s in ctx.shapes]
+        out = torch.empty((n, AG_FP, AG_FP), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = workspace(dev, L.ag_train_weight_grads_workspace_bytes(rows, n))
+        with torch.cuda.device(dev):
+            rc = L.ag_train_weight_grads(n, _ptr_array(dzs), _ptr_array(prevs), (ctypes.c_int32 * 4)(*([p.stride(0) for p in prevs] + [0] * (4 - n))),
+                                         (ctypes.c_int32 * 4)(*(n_ins + [0] * (4 - n))), rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream_ptr(dev))
+        _lib.check(rc, "ag_train_weight_grads")
+        grads = []
+        for l, (n_out, n_in) in enumerate(ctx.shapes):
+            grads += [out[l, :n_out, :n_in], out[l, :n_out, n_in]]
+        return (None, dx[:rows, : ctx.d_in]) + tuple(grads)
+
+
+def fused_chain(kind, x, layers):
+    """kind in CHAIN_KINDS; x (rows, d_in); layers = [(weight, bias)] in order (a weight may be a column slice of a larger
+    parameter, e.g. relation_propagator.linear.weight[:, :nf]).  -> (rows, n_out of the last layer)."""
+    flat = [t for wb in layers for t in wb]
+    return _FusedChain.apply(kind, x, *flat)

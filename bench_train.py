@@ -109,13 +109,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dense-baseline", action="store_true")
+    ap.add_argument("--library-gemm", action="store_true", help="dense stacks through torch F.linear (the r01 path) instead of the fused MFMA chains")
+    ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step in a HIP graph (torch.cuda.graphs) and replay it")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs an MI355X: the graph kernels have no CPU path")
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = TrainableDynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), dev).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.fused_dense = not a.library_gemm
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=a.graph)
     data, csr = synthetic_batch(a.batch, a.max_nobj, dev)
     data.update(Rr=csr, Rs=None, edge_views=EdgeViews(csr))
 
@@ -127,11 +130,34 @@ def main():
         return loss
 
     init = {k: v.clone() for k, v in model.state_dict().items()}
+    if a.graph:
+        # The step has no host synchronisation (edge views are per batch, resolved above), so it captures as ONE HIP graph:
+        # ~300 launches replayed without their host-side launch cost.  Warm up on a side stream first (allocator, packed
+        # weight streams, Adam state), as torch.cuda.graphs requires.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=False)
+        with torch.cuda.graph(g):
+            static_loss = unrolled_loss(model, data, 3)
+            static_loss.backward()
+            opt.step()
+        eager_step = step
+
+        def step():                   # noqa: F811
+            g.replay()
+            return static_loss
     ms, _ = timed(step, a.steps, a.warmup)
     line = {"metric": "training step wall-clock (3-step unroll forward + backward + Adam)", "value": round(ms, 3), "unit": "ms", "n_gpus": 1,
             "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rope key-point graphs, batch {a.batch}, <= {a.max_nobj}+1 nodes, {int(csr.n_rel().sum())} edges in the batch"},
-            "graphs_per_s": round(a.batch / ms * 1e3, 1)}
+            "graphs_per_s": round(a.batch / ms * 1e3, 1),
+            "dense_stacks": "library GEMMs (F.linear)" if a.library_gemm else "fused fp32-MFMA chain kernels (forward + backward)",
+            "hip_graph": bool(a.graph)}
     if a.dense_baseline:
         Rr, Rs = csr.to_dense(torch.float32)
         model.load_state_dict(init)

@@ -152,6 +152,39 @@ int ag_message_forward(const float *eterm, const float *hr, const float *hs, con
 int ag_message_backward(const float *eterm, const float *hr, const float *hs, const int32_t *row_ptr, const int32_t *send,
                         const float *grad_agg, float *grad_edge, float *grad_hr, int64_t n_nodes, int D, ag_stream_t stream);
 
+/* ---- training path, dense stacks (row n4): the Linear(+ReLU) chains of DynamicsPredictor.forward and their backward as fused
+ * exact-fp32 MFMA kernels (activations stay in registers between layers, in both directions).  Replaces the forward/backward of
+ *   AG_CHAIN_EDGE     relation_encoder.model.{0,2,4} (+ReLU each) and relation_propagator.linear[:, :nf] (no ReLU)   model.py:274,289
+ *   AG_CHAIN_NODE     particle_encoder.model.{0,2,4} (+ReLU each)                                                    model.py:268
+ *   AG_CHAIN_DECODER  non_rigid_predictor.linear_{0,1} (+ReLU), linear_2                                             model.py:306
+ * in src/dynamics/train/train.py:90-112 (forward + loss.backward()).
+ *
+ * ag_train_pack: device-side packing of one layer into the kernels' chunk-image format (weights change every optimiser step):
+ *   op(W)[o][k] = transposed ? W[k*ld + col0 + o] : W[o*ld + col0 + k] (o < n_out, k < n_in), bias (nullable) as column n_in;
+ *   `compact` = the single-chunk first-layer image (n_in + 1 <= 32), else `n_tiles` 32-row images; dst gets
+ *   (compact ? 1 : n_tiles) * 5120 floats.  Forward streams hold the layers in order (first layer compact for EDGE/NODE);
+ *   backward streams hold W_{L-1}^T .. W_1^T (5 images each, no bias) then W_0^T (1 image for EDGE/NODE, 5 for DECODER).
+ * ag_train_chain: forward (backward = 0): x ([rows][d_in] dense for EDGE/NODE, [rows_pad][160] for DECODER) -> y[l], l < L, each
+ *   [rows_pad][160] fp32 (rows_pad = rows rounded up to 128; columns >= 150 and padding rows are scratch).  backward = 1:
+ *   dy ([rows_pad][160], gradient w.r.t. y[L-1]) + the saved y[l] -> dz[l] (pre-activation gradients, [rows_pad][160]) and
+ *   dx (same shape as x; nullable for EDGE/NODE).  Weight gradients are dz[l]^T y[l-1] — plain library GEMMs left to the caller.
+ *   `y` / `dz` are HOST arrays of L device pointers. */
+enum { AG_CHAIN_EDGE = 0, AG_CHAIN_NODE = 1, AG_CHAIN_DECODER = 2 };
+int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact, int n_tiles,
+                  float *dst, ag_stream_t stream);
+int ag_train_chain(int kind, int backward, const float *x, const float *packed, float *const *y, const float *dy, float *const *dz,
+                   float *dx, int64_t rows, int d_in, ag_stream_t stream);
+
+/* Weight and bias gradients of up to 4 dense layers in two launches: for layer l,
+ *   out[l][o][k] = sum_rows dz[l][row][o] * prev[l][row][k]   (k < n_in[l])      = d loss / d W_l[o][k]
+ *   out[l][o][n_in[l]] = sum_rows dz[l][row][o]                                   = d loss / d b_l[o]
+ * dz[l] is [rows_pad][160] (ag_train_chain backward), prev[l] the layer's input with row stride prev_ld[l] (>= n_in[l]);
+ * out is [n_layers][160][160] fp32.  Rows are split into slabs, partial sums meet in a fixed order: bit-reproducible.
+ * dz / prev / prev_ld / n_in are HOST arrays. */
+size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers);
+int ag_train_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
+                          int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
  * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
  * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the

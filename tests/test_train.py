@@ -120,6 +120,53 @@ def test_graph_ops_forward_and_adjoint_vs_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,d_in,rows", [("edge", 17, 1000), ("node", 6, 300), ("decoder", 150, 257), ("edge", 17, 1)])
+def test_fused_dense_chain_forward_and_backward_vs_torch(kind, d_in, rows):
+    """The fused exact-fp32 MFMA chain kernels (forward saving every layer, backward with the ReLU masks in registers, weight
+    gradients as one library GEMM per layer) against the same stack in plain torch (fp64 autograd): output, input gradient and
+    every weight / bias gradient; a row count that leaves a partial 128-row tile; repeated calls are bitwise identical."""
+    import torch.nn.functional as F
+    from adaptigraph_amd import train_ops
+    torch.manual_seed(3)
+    n_layers = train_ops.CHAIN_KINDS[kind][1]
+    dims = [d_in] + [150] * (n_layers - 1) + [3 if kind == "decoder" else 150]
+    relu = [True] * (n_layers - 1) + [kind == "node"]
+    big = torch.randn(150, 450, device=DEV) / 12          # the edge chain's last layer is a column slice of a wider parameter
+    Ws = [(torch.randn(dims[l + 1], dims[l], device=DEV) / np.sqrt(dims[l])).requires_grad_() for l in range(n_layers)]
+    if kind == "edge":
+        big.requires_grad_()
+        Ws[-1] = big
+    bs = [(torch.randn(dims[l + 1], device=DEV) * 0.1).requires_grad_() for l in range(n_layers)]
+    x = torch.randn(rows, d_in, device=DEV, requires_grad=True)
+    probe = torch.randn(rows, dims[-1], device=DEV)
+
+    def layers():
+        return [((big[:, :150] if (kind == "edge" and l == n_layers - 1) else Ws[l]), bs[l]) for l in range(n_layers)]
+
+    y = train_ops.fused_chain(kind, x, layers())
+    got = torch.autograd.grad((y * probe).sum(), [x] + Ws + bs)
+    xd = x.detach().double().requires_grad_()
+    Wd = [w.detach().double().requires_grad_() for w in Ws]
+    bd = [b.detach().double().requires_grad_() for b in bs]
+    h = xd
+    for l in range(n_layers):
+        w = Wd[l][:, :150] if (kind == "edge" and l == n_layers - 1) else Wd[l]
+        h = F.linear(h, w, bd[l])
+        h = torch.relu(h) if relu[l] else h
+    ref = torch.autograd.grad((h * probe.double()).sum(), [xd] + Wd + bd)
+    assert y.shape == h.shape and (y.double() - h).abs().max().item() <= 2e-5 * max(1.0, h.abs().max().item())
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and (a.double() - b).abs().max().item() <= 2e-5 * max(1e-3, b.abs().max().item())
+    y2 = train_ops.fused_chain(kind, x, layers())
+    got2 = torch.autograd.grad((y2 * probe).sum(), [x] + Ws + bs)
+    assert torch.equal(y, y2) and all(torch.equal(a, b) for a, b in zip(got, got2))
+    with torch.no_grad():                                    # an in-place parameter update (optimiser step) invalidates the packed streams
+        Ws[0].mul_(0.5)
+    y3 = train_ops.fused_chain(kind, x, layers())
+    assert not torch.equal(y, y3)
+
+
+@pytest.mark.gpu
 def test_unrolled_loss_and_gradients_match_reference(weights):
     from adaptigraph_amd.train_model import unrolled_loss
     g = load_golden("train_rope")
