@@ -108,8 +108,9 @@ def lib():
     L.ag_train_weight_grads_workspace_bytes.restype = c_size_t
     L.ag_train_weight_grads_workspace_bytes.argtypes = [ctypes.c_int64, c_int]
     L.ag_train_weight_grads.restype = c_int
-    L.ag_train_weight_grads.argtypes = [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32),
-                                        ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.ag_train_weight_grads.argtypes = [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_void_p),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]
     L.ag_model_status.restype = c_int
     L.ag_model_status.argtypes = [c_void_p, ctypes.POINTER(c_int), c_void_p]
     L.ag_set_option.restype = c_int

@@ -483,16 +483,16 @@ size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers)
     return ag_weight_grads_ws_floats(rows, n_layers < 1 ? 1 : n_layers) * sizeof(float);
 }
 
-int ag_train_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
+int ag_train_weight_grads(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
                           int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream)
 {
-    if (n_layers < 1 || n_layers > 4 || !dz || !prev || !prev_ld || !n_in || !out || rows < 0) return fail(AG_ERR_ARG, "ag_train_weight_grads: bad argument");
+    if (n_layers < 1 || n_layers > 4 || !dz || !dz_ld || !prev || !prev_ld || !n_in || !out || rows < 0) return fail(AG_ERR_ARG, "ag_train_weight_grads: bad argument");
     for (int l = 0; l < n_layers; ++l)
-        if (!dz[l] || !prev[l] || n_in[l] < 1 || n_in[l] > AG_F || prev_ld[l] < n_in[l])
+        if (!dz[l] || !prev[l] || n_in[l] < 1 || n_in[l] > AG_F || prev_ld[l] < n_in[l] || dz_ld[l] < 1 || dz_ld[l] > AG_FP)
             return fail(AG_ERR_ARG, "ag_train_weight_grads: layer %d: null table or n_in=%d ld=%d", l, n_in[l], prev_ld[l]);
     if (!workspace || workspace_bytes < ag_train_weight_grads_workspace_bytes(rows, n_layers))
         return fail(AG_ERR_WS, "ag_train_weight_grads: workspace %zu < %zu bytes", workspace_bytes, ag_train_weight_grads_workspace_bytes(rows, n_layers));
-    ag_launch_weight_grads(n_layers, dz, prev, prev_ld, n_in, rows, static_cast<float *>(workspace), out, static_cast<hipStream_t>(stream));
+    ag_launch_weight_grads(n_layers, dz, dz_ld, prev, prev_ld, n_in, rows, static_cast<float *>(workspace), out, static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
     return AG_OK;
 }

@@ -128,7 +128,7 @@ void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in
                           int n_tiles, float *dst, hipStream_t s);
 void ag_launch_chain(int kind, int backward, const AgChainArgsPOD &p, int max_blocks, hipStream_t s);
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers);
-void ag_launch_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int *prev_ld, const int *n_in,
+void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_ld, const float *const *prev, const int *prev_ld, const int *n_in,
                             long long rows, float *partial, float *out, hipStream_t s);
 int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
                       int y_batched, float *out, hipStream_t s);

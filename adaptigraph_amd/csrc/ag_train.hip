@@ -78,11 +78,12 @@ __global__ __launch_bounds__(256) void message_bwd_kernel(const float *eterm, co
 // k-tiles, two rows per exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A = dz^T, B = prev; both read as 128-byte row segments), and
 // a second kernel adds the slab partials in ascending slab order: fixed summation order, bit-reproducible, no atomics.
 // The bias gradient rides along as one more k column: prev is read as 1.0 at column n_in.
-constexpr int kDwSlab = 256;            // rows per workgroup
+// rows per workgroup: chosen per call so that slabs x layers ~ 1.5 workgroups per CU (dw_slab_rows); a multiple of 16
 struct DwArgs {
     const float *dz[4], *prev[4];
-    int prev_ld[4], n_in[4];
+    int dz_ld[4], prev_ld[4], n_in[4];
     long long rows;
+    int slab;                            // rows per workgroup
     float *partial;                      // [n_slabs][n_layers][160][160]
     float *out;                          // [n_layers][160][160]: out[l][o][k] = dW_l[o][k] (k < n_in), out[l][o][n_in] = db_l[o]
     int n_slabs, n_layers;
@@ -95,15 +96,15 @@ __global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
     const int slab = blockIdx.x, l = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const float *dz = a.dz[l], *pv = a.prev[l];
-    const int ld = a.prev_ld[l], n_in = a.n_in[l];
+    const int ld = a.prev_ld[l], n_in = a.n_in[l], zld = a.dz_ld[l];
     const int kt = (n_in + 1 + 31) / 32;                  // k-tiles that hold data (incl. the bias column)
     f32x16_t acc[AG_NT];
 #pragma unroll
     for (int t = 0; t < AG_NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    const long long r0 = (long long)slab * kDwSlab;
-    const long long r1 = r0 + kDwSlab < a.rows ? r0 + kDwSlab : a.rows;
+    const long long r0 = (long long)slab * a.slab;
+    const long long r1 = r0 + a.slab < a.rows ? r0 + a.slab : a.rows;
     constexpr int U = 8;                                  // row pairs per iteration: all their loads are issued before the first MFMA
     for (long long rb = r0; rb < r1; rb += 2 * U) {       // lane half h takes row rb + 2u + h (the MFMA's k index)
         float av[U], bv[U][AG_NT];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
         for (int u = 0; u < U; ++u) {
             const long long r = rb + 2 * u + h;
             const bool ok = r < r1;
-            av[u] = ok ? dz[(size_t)r * AG_FP + 32 * w + j] : 0.0f;
+            av[u] = (ok && 32 * w + j < zld) ? dz[(size_t)r * zld + 32 * w + j] : 0.0f;
 #pragma unroll
             for (int t = 0; t < AG_NT; ++t) {
                 const int k = 32 * t + j;
@@ -133,13 +134,23 @@ __global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
             for (int p = 0; p < 4; ++p) dst[(size_t)(32 * w + 8 * q + 4 * h + p) * AG_FP + 32 * t + j] = acc[t][4 * q + p];
 }
 
+// out = sum over slabs, ascending: 32 elements x 8 slab groups per workgroup; group g adds slabs g, g+8, ... in order and the
+// eight group sums meet through LDS in group order — a fixed summation tree, so results are bit-reproducible.
 __global__ __launch_bounds__(256) void dw_reduce_kernel(DwArgs a)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-    if (t >= AG_FP * AG_FP) return;
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5, l = blockIdx.y;
+    const int t = blockIdx.x * 32 + e;
     float s = 0.0f;
-    for (int slab = 0; slab < a.n_slabs; ++slab) s += a.partial[((size_t)slab * a.n_layers + l) * AG_FP * AG_FP + t];
-    a.out[(size_t)l * AG_FP * AG_FP + t] = s;
+    for (int slab = g; slab < a.n_slabs; slab += 8) s += a.partial[((size_t)slab * a.n_layers + l) * AG_FP * AG_FP + t];
+    part[g][e] = s;
+    __syncthreads();
+    if (g == 0) {
+        float r = part[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r += part[k][e];
+        a.out[(size_t)l * AG_FP * AG_FP + t] = r;
+    }
 }
 
 inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
@@ -166,19 +177,27 @@ void ag_launch_message_bwd(const float *eterm, const float *hr, const float *hs,
         hipLaunchKernelGGL(message_bwd_kernel, dim3(blocks_for(N * D)), dim3(256), 0, s, eterm, hr, hs, row_ptr, send, g_agg, g_e, g_hr, N * D, D);
 }
 
+static int dw_slab_rows(long long rows, int n_layers)
+{
+    long long slab = (rows * n_layers + 383) / 384;          // ~384 workgroups in flight
+    slab = (slab + 15) / 16 * 16;
+    return (int)(slab < 32 ? 32 : (slab > 1024 ? 1024 : slab));
+}
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers)
 {
-    const long long slabs = (rows + kDwSlab - 1) / kDwSlab;
+    const int slab = dw_slab_rows(rows, n_layers);
+    const long long slabs = (rows + slab - 1) / slab;
     return (size_t)(slabs > 0 ? slabs : 1) * n_layers * AG_FP * AG_FP;
 }
-void ag_launch_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int *prev_ld, const int *n_in,
+void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_ld, const float *const *prev, const int *prev_ld, const int *n_in,
                             long long rows, float *partial, float *out, hipStream_t s)
 {
     DwArgs a{};
-    for (int l = 0; l < n_layers; ++l) { a.dz[l] = dz[l]; a.prev[l] = prev[l]; a.prev_ld[l] = prev_ld[l]; a.n_in[l] = n_in[l]; }
+    for (int l = 0; l < n_layers; ++l) { a.dz[l] = dz[l]; a.dz_ld[l] = dz_ld[l]; a.prev[l] = prev[l]; a.prev_ld[l] = prev_ld[l]; a.n_in[l] = n_in[l]; }
     a.rows = rows; a.partial = partial; a.out = out; a.n_layers = n_layers;
-    a.n_slabs = (int)((rows + kDwSlab - 1) / kDwSlab);
+    a.slab = dw_slab_rows(rows, n_layers);
+    a.n_slabs = (int)((rows + a.slab - 1) / a.slab);
     if (a.n_slabs < 1) a.n_slabs = 1;
     hipLaunchKernelGGL(dw_partial_kernel, dim3(a.n_slabs, n_layers), dim3(320), 0, s, a);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((AG_FP * AG_FP + 255) / 256, n_layers), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(AG_FP * AG_FP / 32, n_layers), dim3(256), 0, s, a);
 }

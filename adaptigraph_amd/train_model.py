@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .graph import CSREdges, csr_from_dense
 from .model import DynamicsPredictor
-from .train_ops import EdgeViews, fused_chain, gather_receivers, gather_senders, message_sum
+from .train_ops import EdgeViews, fused_chain, gather_receivers, gather_senders, linear, message_sum
 
 
 def _mlp3(block, x):
@@ -65,9 +65,11 @@ class TrainableDynamicsPredictor(DynamicsPredictor):
             enc_e = _mlp3(self.relation_encoder, rel_inputs)                             # :274
             eterm = F.linear(enc_e, w_rp[:, :nf], b_rp)                                  # round-invariant edge term
         h = enc_n
+        lin = linear if self.fused_dense else F.linear
+        pn = lin(enc_n, w_pp[:, :nf], b_pp)                                          # round-invariant block of particle_propagator (:300)
         for _ in range(self.model_config["pstep"]):                                  # :283-301
-            agg = message_sum(eterm, F.linear(h, w_rp[:, nf:2 * nf]), F.linear(h, w_rp[:, 2 * nf:]), views)
-            h = F.relu(F.linear(torch.cat([enc_n, agg], 1), w_pp, b_pp) + h)
+            agg = message_sum(eterm, lin(h, w_rp[:, nf:2 * nf]), lin(h, w_rp[:, 2 * nf:]), views)
+            h = F.relu(lin(agg, w_pp[:, nf:]) + pn + h)
         d = self.non_rigid_predictor
         x = h.reshape(B, N, nf)[:, :n_p].reshape(B * n_p, nf)
         if self.fused_dense:

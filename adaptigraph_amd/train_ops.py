@@ -195,20 +195,51 @@ class _FusedChain(torch.autograd.Function):
         _lib.check(rc, "ag_train_chain(backward)")
         # dW_l = dz_l^T y_{l-1}, db_l = column sums of dz_l: all layers in two launches (row-slab split-K on the fp32 MFMA,
         # fixed-order reduction) — a 150 x 150 output over 10^4..10^5 rows runs on 25 workgroups as a library GEMM
-        prevs = [xin] + ys[:-1]
-        n_ins = [s[1] for s in ctx.shapes]
-        out = torch.empty((n, AG_FP, AG_FP), dtype=torch.float32, device=dev)
-        L = _lib.lib()
-        ws = workspace(dev, L.ag_train_weight_grads_workspace_bytes(rows, n))
-        with torch.cuda.device(dev):
-            rc = L.ag_train_weight_grads(n, _ptr_array(dzs), _ptr_array(prevs), (ctypes.c_int32 * 4)(*([p.stride(0) for p in prevs] + [0] * (4 - n))),
-                                         (ctypes.c_int32 * 4)(*(n_ins + [0] * (4 - n))), rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                         _stream_ptr(dev))
-        _lib.check(rc, "ag_train_weight_grads")
+        out = weight_grads(dzs, [xin] + ys[:-1], [s[1] for s in ctx.shapes], rows)
         grads = []
         for l, (n_out, n_in) in enumerate(ctx.shapes):
             grads += [out[l, :n_out, :n_in], out[l, :n_out, n_in]]
         return (None, dx[:rows, : ctx.d_in]) + tuple(grads)
+
+
+def weight_grads(dzs, prevs, n_ins, rows):
+    """[dz_l (rows+, ld <= 160)], [prev_l (rows+, ld)], [n_in_l] -> (n, 160, 160): out[l, o, k] = sum_rows dz_l[row, o] prev_l[row, k] for
+    k < n_in_l and out[l, o, n_in_l] = sum_rows dz_l[row, o]: weight and bias gradients of up to 4 layers in two launches."""
+    n, dev = len(dzs), dzs[0].device
+    assert 1 <= n <= 4 and all(t.stride(1) == 1 for t in list(dzs) + list(prevs))
+    out = torch.empty((n, AG_FP, AG_FP), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = workspace(dev, L.ag_train_weight_grads_workspace_bytes(rows, n))
+    i32 = lambda v: (ctypes.c_int32 * 4)(*(list(v) + [0] * (4 - n)))
+    with torch.cuda.device(dev):
+        rc = L.ag_train_weight_grads(n, _ptr_array(dzs), i32(t.stride(0) for t in dzs), _ptr_array(prevs), i32(t.stride(0) for t in prevs),
+                                     i32(n_ins), rows, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "ag_train_weight_grads")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b) as a library GEMM, with the weight / bias gradient on the split-K MFMA kernel: for the node-level
+    linears (150 x 150 outputs contracted over ~10^4 rows) hipBLASLt picks a 25-workgroup kernel (75 us per call)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        xs = x if x.stride(1) == 1 else x.contiguous()
+        out = weight_grads([g], [xs], [W.shape[1]], x.shape[0])
+        return g @ W, out[0, : W.shape[0], : W.shape[1]], (out[0, : W.shape[0], W.shape[1]] if ctx.has_bias else None)
+
+
+def linear(x, W, b=None):
+    """F.linear for (rows, <= 150) x (<= 150, <= 150) with rows >> 150 (see _Linear)."""
+    return _Linear.apply(x, W, b)
 
 
 def fused_chain(kind, x, layers):

@@ -178,11 +178,11 @@ int ag_train_chain(int kind, int backward, const float *x, const float *packed, 
 /* Weight and bias gradients of up to 4 dense layers in two launches: for layer l,
  *   out[l][o][k] = sum_rows dz[l][row][o] * prev[l][row][k]   (k < n_in[l])      = d loss / d W_l[o][k]
  *   out[l][o][n_in[l]] = sum_rows dz[l][row][o]                                   = d loss / d b_l[o]
- * dz[l] is [rows_pad][160] (ag_train_chain backward), prev[l] the layer's input with row stride prev_ld[l] (>= n_in[l]);
- * out is [n_layers][160][160] fp32.  Rows are split into slabs, partial sums meet in a fixed order: bit-reproducible.
- * dz / prev / prev_ld / n_in are HOST arrays. */
+ * dz[l] has row stride dz_ld[l] <= 160 (160 for the tables of ag_train_chain backward; n_out for a dense (rows, n_out) gradient),
+ * prev[l] is the layer's input with row stride prev_ld[l] (>= n_in[l]); out is [n_layers][160][160] fp32.  Rows are split into slabs, partial sums meet in a fixed order: bit-reproducible.
+ * dz / dz_ld / prev / prev_ld / n_in are HOST arrays. */
 size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers);
-int ag_train_weight_grads(int n_layers, const float *const *dz, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
+int ag_train_weight_grads(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
                           int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream);
 
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
