@@ -666,13 +666,23 @@ static void part_range(int B, int parts, int k, int *b0, int *nb)
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
 {
     if (!p) return 0;
-    // sized for the unsplit layout, which is the largest (per-part tables are rounded up separately, so add slack)
-    Carver c(nullptr, 0);
-    AgFwdArgs f{};
-    AgEdgeArgs e{};
-    float *a, *b, *d;
-    carve_rollout(c, p, p->B, f, e, &a, &b, &d, AG_NHIS);
-    return align_up(c.off, 256) + (size_t)AG_MAX_PARTS * 64 * 1024 * 1024 / 16;
+    // ag_rollout carves one layout per batch part and the number of parts is a model option ("rollout_streams", 1..4) the
+    // caller may change between this query and the call: size for the largest of the four possible carvings, exactly.
+    size_t need = 0;
+    for (int want = 1; want <= AG_MAX_PARTS; ++want) {
+        const int parts = rollout_parts(p->B, want);
+        Carver c(nullptr, 0);
+        for (int k = 0; k < parts; ++k) {
+            AgFwdArgs f{};
+            AgEdgeArgs e{};
+            float *a, *b, *d;
+            int b0, nb;
+            part_range(p->B, parts, k, &b0, &nb);
+            carve_rollout(c, p, nb, f, e, &a, &b, &d, AG_NHIS);
+        }
+        need = c.off > need ? c.off : need;
+    }
+    return align_up(need, 256);
 }
 
 int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, const float *delta, const float *attrs,

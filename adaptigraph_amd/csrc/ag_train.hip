@@ -74,8 +74,7 @@ __global__ __launch_bounds__(256) void message_bwd_kernel(const float *eterm, co
 // dW_l[o][k] = sum_rows dz_l[row][o] * prev_l[row][k]  and  db_l[o] = sum_rows dz_l[row][o]   (prev_l = input of layer l).
 // The shape defeats library GEMMs: a 150 x 150 output contracted over 10^4..10^5 rows has 25 output tiles, so hipBLASLt ran
 // it on 25 workgroups (88 us per layer, 4.2 of the 10.9 ms training step, profiles/r02_train_trace.txt).  Here the ROWS are split into
-// slabs, one workgroup per (slab, layer): five waves, wave w owns the 32-feature strip o in [32w, 32w+32) against all five
-// k-tiles, two rows per exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A = dz^T, B = prev; both read as 128-byte row segments), and
+// slabs, one wave per (slab, layer, 32-feature strip o in [32w, 32w+32)) against all five k-tiles, two rows per exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A = dz^T, B = prev; both read as 128-byte row segments), and
 // a second kernel adds the slab partials in ascending slab order: fixed summation order, bit-reproducible, no atomics.
 // The bias gradient rides along as one more k column: prev is read as 1.0 at column n_in.
 // rows per workgroup: chosen per call so that slabs x layers ~ 1.5 workgroups per CU (dw_slab_rows); a multiple of 16
@@ -91,13 +90,61 @@ struct DwArgs {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
+// KT = k-tiles that hold data (1 for the narrow first layers, 5 otherwise): compile-time so that the row loop is one
+// straight-line block (a run-time tile count put a branch around every load and MFMA and serialised the loads).
+template <int KT>
+__device__ __forceinline__ void dw_rows(const DwArgs &a, int l, long long r0, long long r1, int w, int j, int h, f32x16_t (&acc)[AG_NT])
 {
-    const int slab = blockIdx.x, l = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
     const float *dz = a.dz[l], *pv = a.prev[l];
     const int ld = a.prev_ld[l], n_in = a.n_in[l], zld = a.dz_ld[l];
-    const int kt = (n_in + 1 + 31) / 32;                  // k-tiles that hold data (incl. the bias column)
+    constexpr int U = 4;                                  // row pairs per fetch; double-buffered: the loads of the next U pairs are
+    const int zc = 32 * w + j < zld ? 32 * w + j : zld - 1;   // issued before the MFMAs of the current ones
+    const float zokf = 32 * w + j < zld ? 1.0f : 0.0f;
+    int kc[KT];
+    float kinf[KT], kone[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int k = 32 * t + j;
+        kinf[t] = k < n_in ? 1.0f : 0.0f; kc[t] = k < n_in ? k : n_in - 1; kone[t] = k == n_in ? 1.0f : 0.0f;   // column n_in reads as 1 (bias gradient)
+    }
+    auto fetch = [&](long long rb, float (&av)[U], float (&bv)[U][KT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rb + 2 * u + h;           // lane half h takes row rb + 2u + h (the MFMA's k index)
+            // Always a valid (clamped) address, loads unconditional, values masked ARITHMETICALLY: written as selects, the
+            // compiler sinks each load under its own branch and the 24 loads of a fetch serialise.
+            const float okf = r < r1 ? 1.0f : 0.0f;
+            const long long rc = r < r1 ? r : r1 - 1;
+            av[u] = dz[(size_t)rc * zld + zc] * (okf * zokf);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bv[u][t] = (pv[(size_t)rc * ld + kc[t]] * kinf[t] + kone[t]) * okf;
+        }
+    };
+    auto fma_all = [&](const float (&av)[U], const float (&bv)[U][KT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    };
+    float a0[U], b0[U][KT], a1[U], b1[U][KT];
+    fetch(r0, a0, b0);
+    for (long long rb = r0; rb < r1; rb += 4 * U) {
+        fetch(rb + 2 * U, a1, b1);
+        fma_all(a0, b0);
+        fetch(rb + 4 * U, a0, b0);
+        fma_all(a1, b1);
+    }
+}
+
+// One WAVE per (slab, layer, 32-feature strip) task, four tasks per 256-thread workgroup: ~2 000 equal tasks fill the 1 024
+// SIMDs two deep whatever the layer count (five-wave workgroups of one slab each left a SIMD with two waves and the others
+// with one, and 380 workgroups on 256 CUs ran in two uneven rounds: 269 us for the edge chain vs 55 us of fp32 MFMA time).
+__global__ __launch_bounds__(256) void dw_partial_kernel(DwArgs a)
+{
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= a.n_slabs * a.n_layers * AG_NT) return;
+    const int w = task % AG_NT, sl = task / AG_NT, l = sl % a.n_layers, slab = sl / a.n_layers;
     f32x16_t acc[AG_NT];
 #pragma unroll
     for (int t = 0; t < AG_NT; ++t)
@@ -105,25 +152,9 @@ __global__ __launch_bounds__(320) void dw_partial_kernel(DwArgs a)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const long long r0 = (long long)slab * a.slab;
     const long long r1 = r0 + a.slab < a.rows ? r0 + a.slab : a.rows;
-    constexpr int U = 8;                                  // row pairs per iteration: all their loads are issued before the first MFMA
-    for (long long rb = r0; rb < r1; rb += 2 * U) {       // lane half h takes row rb + 2u + h (the MFMA's k index)
-        float av[U], bv[U][AG_NT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long r = rb + 2 * u + h;
-            const bool ok = r < r1;
-            av[u] = (ok && 32 * w + j < zld) ? dz[(size_t)r * zld + 32 * w + j] : 0.0f;
-#pragma unroll
-            for (int t = 0; t < AG_NT; ++t) {
-                const int k = 32 * t + j;
-                bv[u][t] = (ok && t < kt) ? (k < n_in ? pv[(size_t)r * ld + k] : (k == n_in ? 1.0f : 0.0f)) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < AG_NT; ++t)
-                if (t < kt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    if (r0 < r1) {
+        if (a.n_in[l] + 1 <= 32) dw_rows<1>(a, l, r0, r1, w, j, h, acc);
+        else dw_rows<AG_NT>(a, l, r0, r1, w, j, h, acc);
     }
     float *dst = a.partial + ((size_t)slab * a.n_layers + l) * AG_FP * AG_FP;
 #pragma unroll
@@ -179,9 +210,9 @@ void ag_launch_message_bwd(const float *eterm, const float *hr, const float *hs,
 
 static int dw_slab_rows(long long rows, int n_layers)
 {
-    long long slab = (rows * n_layers + 383) / 384;          // ~384 workgroups in flight
+    long long slab = (rows * n_layers * AG_NT + 2047) / 2048;          // ~2 048 wave tasks = two per SIMD
     slab = (slab + 15) / 16 * 16;
-    return (int)(slab < 32 ? 32 : (slab > 1024 ? 1024 : slab));
+    return (int)(slab < 64 ? 64 : (slab > 2048 ? 2048 : slab));       // >= 64 rows per task: bounds the partial-sum traffic of small problems
 }
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers)
 {
@@ -198,6 +229,6 @@ void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_
     a.slab = dw_slab_rows(rows, n_layers);
     a.n_slabs = (int)((rows + a.slab - 1) / a.slab);
     if (a.n_slabs < 1) a.n_slabs = 1;
-    hipLaunchKernelGGL(dw_partial_kernel, dim3(a.n_slabs, n_layers), dim3(320), 0, s, a);
+    hipLaunchKernelGGL(dw_partial_kernel, dim3((a.n_slabs * n_layers * AG_NT + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(AG_FP * AG_FP / 32, n_layers), dim3(256), 0, s, a);
 }

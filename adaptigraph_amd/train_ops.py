@@ -151,6 +151,20 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * 4)(*([t.data_ptr() for t in tensors] + [None] * (4 - len(tensors))))
 
 
+_ZEROS = {}
+
+
+def _zero_padded(tag, rows_pad, dev):
+    """A (rows_pad, 160) fp32 buffer whose every element outside the block a caller overwrites is zero.  One per (tag, shape):
+    callers overwrite the SAME live block each time and consume the buffer on the same stream before the next use."""
+    key = (tag, rows_pad, dev.index)
+    buf = _ZEROS.get(key)
+    if buf is None:
+        buf = torch.zeros((rows_pad, AG_FP), dtype=torch.float32, device=dev)
+        _ZEROS[key] = buf
+    return buf
+
+
 class _FusedChain(torch.autograd.Function):
     """y = layer_{L-1}(... layer_0(x)) with the kind's fixed widths and ReLU pattern; saves every layer output, backward =
     one fused kernel for the input / pre-activation gradients + one library GEMM and one column sum per layer."""
@@ -165,7 +179,7 @@ class _FusedChain(torch.autograd.Function):
         rows_pad = max(_ROW_TILE, -(-rows // _ROW_TILE) * _ROW_TILE)
         fwd, bwd = _pack_chain(kind, [(W.detach(), b.detach()) for W, b in layers], dev)
         if kind == "decoder":
-            xin = x.new_zeros((rows_pad, AG_FP))
+            xin = x.new_zeros((rows_pad, AG_FP))                    # saved for the backward: a fresh table per call
             xin[:rows, : x.shape[1]] = x
         else:
             xin = x.contiguous().float()
@@ -185,7 +199,7 @@ class _FusedChain(torch.autograd.Function):
         code, n = CHAIN_KINDS[ctx.kind]
         dev, rows = xin.device, ctx.rows
         rows_pad = ys[0].shape[0]
-        dy = torch.zeros((rows_pad, AG_FP), dtype=torch.float32, device=dev)
+        dy = _zero_padded("dy_" + ctx.kind, rows_pad, dev)                  # columns >= n_out and padding rows stay zero: only the live block is written
         dy[:rows, : grad_out.shape[1]] = grad_out
         dzs = [torch.empty((rows_pad, AG_FP), dtype=torch.float32, device=dev) for _ in range(n)]
         dx = torch.empty_like(xin)
