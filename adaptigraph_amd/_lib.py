@@ -101,9 +101,9 @@ def lib():
     L.ag_chamfer_masked.restype = c_int
     L.ag_chamfer_masked.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.ag_train_pack.restype = c_int
-    L.ag_train_pack.argtypes = [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]
+    L.ag_train_pack.argtypes = [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]
     L.ag_train_chain.restype = c_int
-    L.ag_train_chain.argtypes = [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+    L.ag_train_chain.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, ctypes.POINTER(c_void_p), c_void_p,
                                  ctypes.c_int64, c_int, c_void_p]
     L.ag_train_weight_grads_workspace_bytes.restype = c_size_t
     L.ag_train_weight_grads_workspace_bytes.argtypes = [ctypes.c_int64, c_int]

@@ -442,19 +442,19 @@ int ag_message_backward(const float *eterm, const float *hr, const float *hs, co
 }
 
 int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact, int n_tiles,
-                  float *dst, ag_stream_t stream)
+                  int precision, float *dst, ag_stream_t stream)
 {
     if (!W || !dst) return fail(AG_ERR_ARG, "ag_train_pack: null argument");
     if (n_out < 1 || n_in < 1 || n_in > AG_F || ld < 1 || col0 < 0 || n_tiles < 1 || n_tiles > AG_NT || n_out > 32 * n_tiles * (compact ? AG_NT : 1))
         return fail(AG_ERR_ARG, "ag_train_pack: bad sizes n_out=%d n_in=%d ld=%d n_tiles=%d", n_out, n_in, ld, n_tiles);
     if (compact && n_in + (bias ? 1 : 0) > 32) return fail(AG_ERR_ARG, "ag_train_pack: compact image holds <= 32 input columns");
-    ag_launch_train_pack(W, bias, n_out, n_in, ld, col0, transposed ? 1 : 0, compact ? 1 : 0, n_tiles, dst, static_cast<hipStream_t>(stream));
+    ag_launch_train_pack(W, bias, n_out, n_in, ld, col0, transposed ? 1 : 0, compact ? 1 : 0, n_tiles, precision ? 1 : 0, dst, static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
     return AG_OK;
 }
 
-int ag_train_chain(int kind, int backward, const float *x, const float *packed, float *const *y, const float *dy, float *const *dz,
-                   float *dx, int64_t rows, int d_in, ag_stream_t stream)
+int ag_train_chain(int kind, int backward, int precision, const float *x, const float *packed, float *const *y, const float *dy,
+                   float *const *dz, float *dx, int64_t rows, int d_in, ag_stream_t stream)
 {
     if (kind < AG_CHAIN_EDGE || kind > AG_CHAIN_DECODER) return fail(AG_ERR_ARG, "ag_train_chain: bad kind %d", kind);
     const int L = kind == AG_CHAIN_EDGE ? 4 : 3;
@@ -473,7 +473,7 @@ int ag_train_chain(int kind, int backward, const float *x, const float *packed, 
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    ag_launch_chain(kind, backward ? 1 : 0, p, AG_MLP_WG_PER_CU * cus, static_cast<hipStream_t>(stream));
+    ag_launch_chain(kind, backward ? 1 : 0, precision ? 1 : 0, p, AG_MLP_WG_PER_CU * cus, static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
     return AG_OK;
 }

@@ -1275,7 +1275,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 
 // =====================================================================================================
 // Training path: the dense stacks of DynamicsPredictor.forward and their backward on the
-// same fused-layer machinery, exact fp32 MFMA (PrecF32: gradients have to match the reference's fp32 autograd).
+// same fused-layer machinery, in either arithmetic: exact fp32 MFMA (PrecF32) or split-bf16 (PrecB3: 2^-17 relative operand
+// error, measured well inside the 2e-4 gradient gate of tests/golden/train_rope.npz, ~5x the MFMA rate; default).
 //   forward  y_l = act_l(W_l y_{l-1} + b_l), l = 0..L-1, every y_l stored (row-major [rows][160]) for the backward
 //   backward dz_l = dy_l (.) [y_l > 0] (ReLU layers), dy_{l-1} = dz_l W_l — again a chain of fused layers, with the
 //            TRANSPOSED weights as the MFMA A operand and the ReLU mask applied in registers from the saved y_{l-1};
@@ -1319,11 +1320,10 @@ struct MaskStore {   // sink of a backward layer: dz = dy (.) [y > 0] (if MASK),
     }
 };
 
-template <int KIND>
+template <int KIND, class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void chain_forward_kernel(AgChainArgs a)
 {
     typedef ChainShape<KIND> S;
-    typedef PrecF32 Prec;
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const long long ntiles = (a.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
@@ -1367,11 +1367,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void chain_forwar
     }
 }
 
-template <int KIND>
+template <int KIND, class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void chain_backward_kernel(AgChainArgs a)
 {
     typedef ChainShape<KIND> S;
-    typedef PrecF32 Prec;
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const long long ntiles = (a.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
@@ -1442,6 +1441,31 @@ __global__ __launch_bounds__(256) void train_pack_kernel(const float *W, const f
     dst[t] = v;
 }
 
+// the same layers as split-bf16 fragment images (PrecB3): one thread per weight, writing its hi and lo halves;
+//   standard image [10 steps u][hi|lo][64 lanes (i, h)][8 slots e], slot e = column 16u + 8(e>>2) + 4h + (e&3);
+//   compact first-layer image [5 tiles][NU][hi|lo][64][8] with NU = ceil((n_in + 1) / 16) <= 2
+__global__ __launch_bounds__(256) void train_pack_b3_kernel(const float *W, const float *bias, int n_out, int n_in, int ld, int col0,
+                                                            int transposed, int compact, int n_tiles, float *dst)
+{
+    const int NU = compact ? (n_in + 1 + 15) / 16 : 10;
+    const int per_tile = NU * 512;                            // (u, lane, e) triples per 32-row tile
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (compact ? AG_NT : n_tiles) * per_tile) return;
+    const int tile = t / per_tile, r = t % per_tile, u = r / 512, lane = (r % 512) / 8, e = r % 8;
+    const int i = lane & 31, h = lane >> 5, k = 16 * u + 8 * (e >> 2) + 4 * h + (e & 3), o = 32 * tile + i;
+    float v = 0.0f;
+    if (o < n_out) {
+        if (k < n_in) v = transposed ? W[(size_t)k * ld + col0 + o] : W[(size_t)o * ld + col0 + k];
+        else if (k == n_in && bias) v = bias[o];
+    }
+    const unsigned hp = cvt_pk_bf16(v, 0.0f) & 0xffffu;
+    const unsigned lp = cvt_pk_bf16(v - __uint_as_float(hp << 16), 0.0f) & 0xffffu;
+    unsigned short *cb = reinterpret_cast<unsigned short *>(dst);
+    const size_t base = compact ? (size_t)((tile * NU + u) * 2) * 512 : (size_t)tile * (AG_CHUNK_FLOATS * 2) + (size_t)(2 * u) * 512;
+    cb[base + lane * 8 + e] = (unsigned short)hp;
+    cb[base + 512 + lane * 8 + e] = (unsigned short)lp;
+}
+
 }  // namespace
 
 #if AG_TRACE
@@ -1492,21 +1516,35 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
 }
 
 void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact,
-                          int n_tiles, float *dst, hipStream_t s)
+                          int n_tiles, int b3, float *dst, hipStream_t s)
 {
+    if (b3) {
+        if (compact) (void)hipMemsetAsync(dst, 0, AG_CHUNK_FLOATS * sizeof(float), s);      // the compact image has unused tail bytes when NU = 1
+        const int total = (compact ? AG_NT * ((n_in + 1 + 15) / 16) : n_tiles * 10) * 512;
+        hipLaunchKernelGGL(train_pack_b3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, bias, n_out, n_in, ld, col0, transposed, compact, n_tiles, dst);
+        return;
+    }
     const int total = (compact ? 1 : n_tiles) * AG_CHUNK_FLOATS;
     hipLaunchKernelGGL(train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, bias, n_out, n_in, ld, col0, transposed, compact, n_tiles, dst);
 }
 
-void ag_launch_chain(int kind, int backward, const AgChainArgsPOD &p, int max_blocks, hipStream_t s)
+void ag_launch_chain(int kind, int backward, int b3, const AgChainArgsPOD &p, int max_blocks, hipStream_t s)
 {
     AgChainArgs a;
     a.x = p.x; a.w = reinterpret_cast<const float4 *>(p.w); a.dy = p.dy; a.dx = p.dx; a.rows = p.rows; a.d_in = p.d_in;
     for (int l = 0; l < 4; ++l) { a.y[l] = p.y[l]; a.dz[l] = p.dz[l]; }
     const long long tiles = (p.rows + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     const dim3 grid((unsigned)(tiles < max_blocks ? (tiles > 0 ? tiles : 1) : max_blocks)), block(AG_MLP_THREADS);
-#define AG_CHAIN_CASE(K) \
-    case K: if (backward) hipLaunchKernelGGL(chain_backward_kernel<K>, grid, block, 0, s, a); else hipLaunchKernelGGL(chain_forward_kernel<K>, grid, block, 0, s, a); break;
-    switch (kind) { AG_CHAIN_CASE(0) AG_CHAIN_CASE(1) AG_CHAIN_CASE(2) default: break; }
+#define AG_CHAIN_CASE(K, P) \
+    if (backward) hipLaunchKernelGGL((chain_backward_kernel<K, P>), grid, block, 0, s, a); else hipLaunchKernelGGL((chain_forward_kernel<K, P>), grid, block, 0, s, a);
+    switch (kind * 2 + (b3 ? 1 : 0)) {
+    case 0: AG_CHAIN_CASE(0, PrecF32) break;
+    case 1: AG_CHAIN_CASE(0, PrecB3) break;
+    case 2: AG_CHAIN_CASE(1, PrecF32) break;
+    case 3: AG_CHAIN_CASE(1, PrecB3) break;
+    case 4: AG_CHAIN_CASE(2, PrecF32) break;
+    case 5: AG_CHAIN_CASE(2, PrecB3) break;
+    default: break;
+    }
 #undef AG_CHAIN_CASE
 }

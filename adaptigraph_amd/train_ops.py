@@ -111,16 +111,18 @@ def message_sum(eterm, hr, hs, views):
 # ---------------------------------------------------------------------------------------------------------------------
 AG_FP, _ROW_TILE, _CHUNK = 160, 128, 5120
 CHAIN_KINDS = {"edge": (0, 4), "node": (1, 3), "decoder": (2, 3)}      # name -> (AG_CHAIN_*, layers)
+CHAIN_PRECISION = 1     # 1: split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulate; default); 0: exact fp32 MFMA
 _PACK_CACHE = {}
 
 
 def _pack_chain(kind, layers, dev):
     """Pack [(W, b)] into the forward stream and the transposed backward stream (device-side, one launch per layer), cached
     until a parameter is updated in place (optimiser step) or replaced."""
-    key = (kind, dev.index) + tuple((W.data_ptr(), W._version, b.data_ptr(), b._version) for W, b in layers)
+    prec = int(CHAIN_PRECISION)
+    key = (kind, dev.index, prec) + tuple((W.data_ptr(), W._version, b.data_ptr(), b._version) for W, b in layers)
     hit = _PACK_CACHE.get((kind, dev.index))
     if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+        return hit[1], hit[2], prec
     L = _lib.lib()
     narrow = kind != "decoder"
     n = len(layers)
@@ -133,7 +135,7 @@ def _pack_chain(kind, layers, dev):
             n_out, n_in = W.shape
             assert W.stride(1) == 1 and b.is_contiguous()
             compact = narrow and l == 0
-            _lib.check(L.ag_train_pack(W.data_ptr(), b.data_ptr(), n_out, n_in, W.stride(0), 0, 0, int(compact), 1 if compact else 5,
+            _lib.check(L.ag_train_pack(W.data_ptr(), b.data_ptr(), n_out, n_in, W.stride(0), 0, 0, int(compact), 1 if compact else 5, prec,
                                        fwd.data_ptr() + 4 * off, st), "ag_train_pack")
             off += _CHUNK * (1 if compact else 5)
         off = 0
@@ -141,10 +143,10 @@ def _pack_chain(kind, layers, dev):
             W, _ = layers[l]
             n_out, n_in = W.shape
             tiles = 1 if (narrow and l == 0) else 5
-            _lib.check(L.ag_train_pack(W.data_ptr(), None, n_in, n_out, W.stride(0), 0, 1, 0, tiles, bwd.data_ptr() + 4 * off, st), "ag_train_pack")
+            _lib.check(L.ag_train_pack(W.data_ptr(), None, n_in, n_out, W.stride(0), 0, 1, 0, tiles, prec, bwd.data_ptr() + 4 * off, st), "ag_train_pack")
             off += _CHUNK * tiles
     _PACK_CACHE[(kind, dev.index)] = (key, fwd, bwd)
-    return fwd, bwd
+    return fwd, bwd, prec
 
 
 def _ptr_array(tensors):
@@ -177,7 +179,7 @@ class _FusedChain(torch.autograd.Function):
         dev = x.device
         rows = x.shape[0]
         rows_pad = max(_ROW_TILE, -(-rows // _ROW_TILE) * _ROW_TILE)
-        fwd, bwd = _pack_chain(kind, [(W.detach(), b.detach()) for W, b in layers], dev)
+        fwd, bwd, prec = _pack_chain(kind, [(W.detach(), b.detach()) for W, b in layers], dev)
         if kind == "decoder":
             xin = x.new_zeros((rows_pad, AG_FP))                    # saved for the backward: a fresh table per call
             xin[:rows, : x.shape[1]] = x
@@ -185,10 +187,10 @@ class _FusedChain(torch.autograd.Function):
             xin = x.contiguous().float()
         ys = [torch.empty((rows_pad, AG_FP), dtype=torch.float32, device=dev) for _ in range(n)]
         with torch.cuda.device(dev):
-            rc = _lib.lib().ag_train_chain(code, 0, xin.data_ptr(), fwd.data_ptr(), _ptr_array(ys), None, _ptr_array([]), None, rows,
+            rc = _lib.lib().ag_train_chain(code, 0, prec, xin.data_ptr(), fwd.data_ptr(), _ptr_array(ys), None, _ptr_array([]), None, rows,
                                            x.shape[1], _stream_ptr(dev))
         _lib.check(rc, "ag_train_chain(forward)")
-        ctx.kind, ctx.rows, ctx.d_in, ctx.bwd = kind, rows, x.shape[1], bwd
+        ctx.kind, ctx.rows, ctx.d_in, ctx.bwd, ctx.prec = kind, rows, x.shape[1], bwd, prec
         ctx.shapes = [tuple(W.shape) for W, _ in layers]
         ctx.save_for_backward(xin, *ys)
         return ys[-1][:rows, : layers[-1][0].shape[0]]
@@ -204,7 +206,7 @@ class _FusedChain(torch.autograd.Function):
         dzs = [torch.empty((rows_pad, AG_FP), dtype=torch.float32, device=dev) for _ in range(n)]
         dx = torch.empty_like(xin)
         with torch.cuda.device(dev):
-            rc = _lib.lib().ag_train_chain(code, 1, xin.data_ptr(), ctx.bwd.data_ptr(), _ptr_array(ys), dy.data_ptr(), _ptr_array(dzs),
+            rc = _lib.lib().ag_train_chain(code, 1, ctx.prec, xin.data_ptr(), ctx.bwd.data_ptr(), _ptr_array(ys), dy.data_ptr(), _ptr_array(dzs),
                                            dx.data_ptr(), rows, ctx.d_in, _stream_ptr(dev))
         _lib.check(rc, "ag_train_chain(backward)")
         # dW_l = dz_l^T y_{l-1}, db_l = column sums of dz_l: all layers in two launches (row-slab split-K on the fp32 MFMA,

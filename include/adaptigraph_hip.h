@@ -168,12 +168,14 @@ int ag_message_backward(const float *eterm, const float *hr, const float *hs, co
  *   [rows_pad][160] fp32 (rows_pad = rows rounded up to 128; columns >= 150 and padding rows are scratch).  backward = 1:
  *   dy ([rows_pad][160], gradient w.r.t. y[L-1]) + the saved y[l] -> dz[l] (pre-activation gradients, [rows_pad][160]) and
  *   dx (same shape as x; nullable for EDGE/NODE).  Weight gradients are dz[l]^T y[l-1] — plain library GEMMs left to the caller.
- *   `y` / `dz` are HOST arrays of L device pointers. */
+ *   `y` / `dz` are HOST arrays of L device pointers.
+ * `precision`: 0 = exact fp32 MFMA, non-zero = split-bf16 (as the inference engine's mode 1); the packed stream and the chain call
+ *   must use the same value. */
 enum { AG_CHAIN_EDGE = 0, AG_CHAIN_NODE = 1, AG_CHAIN_DECODER = 2 };
 int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact, int n_tiles,
-                  float *dst, ag_stream_t stream);
-int ag_train_chain(int kind, int backward, const float *x, const float *packed, float *const *y, const float *dy, float *const *dz,
-                   float *dx, int64_t rows, int d_in, ag_stream_t stream);
+                  int precision, float *dst, ag_stream_t stream);
+int ag_train_chain(int kind, int backward, int precision, const float *x, const float *packed, float *const *y, const float *dy,
+                   float *const *dz, float *dx, int64_t rows, int d_in, ag_stream_t stream);
 
 /* Weight and bias gradients of up to 4 dense layers in two launches: for layer l,
  *   out[l][o][k] = sum_rows dz[l][row][o] * prev[l][row][k]   (k < n_in[l])      = d loss / d W_l[o][k]

@@ -120,13 +120,17 @@ def test_graph_ops_forward_and_adjoint_vs_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("kind,d_in,rows", [("edge", 17, 1000), ("node", 6, 300), ("decoder", 150, 257), ("edge", 17, 1)])
-def test_fused_dense_chain_forward_and_backward_vs_torch(kind, d_in, rows):
-    """The fused exact-fp32 MFMA chain kernels (forward saving every layer, backward with the ReLU masks in registers, weight
-    gradients as one library GEMM per layer) against the same stack in plain torch (fp64 autograd): output, input gradient and
-    every weight / bias gradient; a row count that leaves a partial 128-row tile; repeated calls are bitwise identical."""
+def test_fused_dense_chain_forward_and_backward_vs_torch(kind, d_in, rows, precision, monkeypatch):
+    """The fused MFMA chain kernels (forward saving every layer, backward with the ReLU masks in registers, weight gradients on
+    the split-K MFMA kernel), in both arithmetic modes (split-bf16 default, exact fp32), against the same stack in plain torch
+    (fp64 autograd): output, input gradient and every weight / bias gradient; a row count that leaves a partial 128-row tile;
+    repeated calls are bitwise identical."""
     import torch.nn.functional as F
     from adaptigraph_amd import train_ops
+    monkeypatch.setattr(train_ops, "CHAIN_PRECISION", precision)
+    tol = 2e-5 if precision == 0 else 1e-4          # split-bf16: 2^-17 relative operand error (gradient gate of the golden: 2e-4)
     torch.manual_seed(3)
     n_layers = train_ops.CHAIN_KINDS[kind][1]
     dims = [d_in] + [150] * (n_layers - 1) + [3 if kind == "decoder" else 150]
@@ -154,9 +158,9 @@ def test_fused_dense_chain_forward_and_backward_vs_torch(kind, d_in, rows):
         h = F.linear(h, w, bd[l])
         h = torch.relu(h) if relu[l] else h
     ref = torch.autograd.grad((h * probe.double()).sum(), [xd] + Wd + bd)
-    assert y.shape == h.shape and (y.double() - h).abs().max().item() <= 2e-5 * max(1.0, h.abs().max().item())
+    assert y.shape == h.shape and (y.double() - h).abs().max().item() <= tol * max(1.0, h.abs().max().item())
     for a, b in zip(got, ref):
-        assert a.shape == b.shape and (a.double() - b).abs().max().item() <= 2e-5 * max(1e-3, b.abs().max().item())
+        assert a.shape == b.shape and (a.double() - b).abs().max().item() <= tol * max(1e-3, b.abs().max().item())
     y2 = train_ops.fused_chain(kind, x, layers())
     got2 = torch.autograd.grad((y2 * probe).sum(), [x] + Ws + bs)
     assert torch.equal(y, y2) and all(torch.equal(a, b) for a, b in zip(got, got2))
