@@ -478,6 +478,22 @@ int ag_train_chain(int kind, int backward, int precision, const float *x, const 
     return AG_OK;
 }
 
+int ag_add3_relu(const float *a, const float *b, const float *c, float *y, int64_t n, ag_stream_t stream)
+{
+    if (n < 0 || (n & 3) || (n > 0 && (!a || !b || !c || !y))) return fail(AG_ERR_ARG, "ag_add3_relu: n=%lld must be a non-negative multiple of 4, tensors non-null", (long long)n);
+    ag_launch_add3_relu(a, b, c, y, n, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_relu_mask(const float *g, const float *y, float *out, int64_t n, ag_stream_t stream)
+{
+    if (n < 0 || (n & 3) || (n > 0 && (!g || !y || !out))) return fail(AG_ERR_ARG, "ag_relu_mask: n=%lld must be a non-negative multiple of 4, tensors non-null", (long long)n);
+    ag_launch_relu_mask(g, y, out, n, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers)
 {
     return ag_weight_grads_ws_floats(rows, n_layers < 1 ? 1 : n_layers) * sizeof(float);

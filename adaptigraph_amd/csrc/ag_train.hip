@@ -97,7 +97,7 @@ __device__ __forceinline__ void dw_rows(const DwArgs &a, int l, long long r0, lo
 {
     const float *dz = a.dz[l], *pv = a.prev[l];
     const int ld = a.prev_ld[l], n_in = a.n_in[l], zld = a.dz_ld[l];
-    constexpr int U = 4;                                  // row pairs per fetch; double-buffered: the loads of the next U pairs are
+    constexpr int U = 4;                                  // row pairs per fetch (U = 8 needs 304 registers: one wave per SIMD); double-buffered: the loads of the next U pairs are
     const int zc = 32 * w + j < zld ? 32 * w + j : zld - 1;   // issued before the MFMAs of the current ones
     const float zokf = 32 * w + j < zld ? 1.0f : 0.0f;
     int kc[KT];
@@ -139,7 +139,7 @@ __device__ __forceinline__ void dw_rows(const DwArgs &a, int l, long long r0, lo
 // One WAVE per (slab, layer, 32-feature strip) task, four tasks per 256-thread workgroup: ~2 000 equal tasks fill the 1 024
 // SIMDs two deep whatever the layer count (five-wave workgroups of one slab each left a SIMD with two waves and the others
 // with one, and 380 workgroups on 256 CUs ran in two uneven rounds: 269 us for the edge chain vs 55 us of fp32 MFMA time).
-__global__ __launch_bounds__(256) void dw_partial_kernel(DwArgs a)
+__global__ __launch_bounds__(256, 2) void dw_partial_kernel(DwArgs a)
 {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -184,6 +184,22 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwArgs a)
     }
 }
 
+// y = relu(a + b + c) and its adjoint g * [y > 0] — the node update's residual (model.py:36-40) as one launch each way
+__global__ __launch_bounds__(256) void add3_relu_kernel(const float4 *a, const float4 *b, const float4 *c, float4 *y, long long n4)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const float4 u = a[t], v = b[t], w = c[t];
+    y[t] = make_float4(fmaxf((u.x + v.x) + w.x, 0.f), fmaxf((u.y + v.y) + w.y, 0.f), fmaxf((u.z + v.z) + w.z, 0.f), fmaxf((u.w + v.w) + w.w, 0.f));
+}
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float4 *g, const float4 *y, float4 *out, long long n4)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4) return;
+    const float4 u = g[t], v = y[t];
+    out[t] = make_float4(v.x > 0.f ? u.x : 0.f, v.y > 0.f ? u.y : 0.f, v.z > 0.f ? u.z : 0.f, v.w > 0.f ? u.w : 0.f);
+}
+
 inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -212,7 +228,7 @@ static int dw_slab_rows(long long rows, int n_layers)
 {
     long long slab = (rows * n_layers * AG_NT + 2047) / 2048;          // ~2 048 wave tasks = two per SIMD
     slab = (slab + 15) / 16 * 16;
-    return (int)(slab < 64 ? 64 : (slab > 2048 ? 2048 : slab));       // >= 64 rows per task: bounds the partial-sum traffic of small problems
+    return (int)(slab < 64 ? 64 : (slab > 2048 ? 2048 : slab));       // >= 64 rows per task bounds the partial-sum traffic; a 256-row floor (4x fewer tasks) measured 17 % slower end to end
 }
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers)
 {
@@ -231,4 +247,15 @@ void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_
     if (a.n_slabs < 1) a.n_slabs = 1;
     hipLaunchKernelGGL(dw_partial_kernel, dim3((a.n_slabs * n_layers * AG_NT + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(AG_FP * AG_FP / 32, n_layers), dim3(256), 0, s, a);
+}
+
+void ag_launch_add3_relu(const float *a, const float *b, const float *c, float *y, long long n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(add3_relu_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(a),
+                                  reinterpret_cast<const float4 *>(b), reinterpret_cast<const float4 *>(c), reinterpret_cast<float4 *>(y), n / 4);
+}
+void ag_launch_relu_mask(const float *g, const float *y, float *out, long long n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks_for(n / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(g),
+                                  reinterpret_cast<const float4 *>(y), reinterpret_cast<float4 *>(out), n / 4);
 }

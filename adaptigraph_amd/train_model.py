@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .graph import CSREdges, csr_from_dense
 from .model import DynamicsPredictor
-from .train_ops import EdgeViews, fused_chain, gather_receivers, gather_senders, linear, message_sum
+from .train_ops import EdgeViews, add3_relu, fused_chain, gather_receivers, gather_senders, linear, linear2, message_sum
 
 
 def _mlp3(block, x):
@@ -68,8 +68,12 @@ class TrainableDynamicsPredictor(DynamicsPredictor):
         lin = linear if self.fused_dense else F.linear
         pn = lin(enc_n, w_pp[:, :nf], b_pp)                                          # round-invariant block of particle_propagator (:300)
         for _ in range(self.model_config["pstep"]):                                  # :283-301
-            agg = message_sum(eterm, lin(h, w_rp[:, nf:2 * nf]), lin(h, w_rp[:, 2 * nf:]), views)
-            h = F.relu(lin(agg, w_pp[:, nf:]) + pn + h)
+            if self.fused_dense and (M * nf) % 4 == 0:
+                hr, hs = linear2(h, w_rp[:, nf:2 * nf], w_rp[:, 2 * nf:])
+                h = add3_relu(lin(message_sum(eterm, hr, hs, views), w_pp[:, nf:]), pn, h)
+            else:
+                agg = message_sum(eterm, lin(h, w_rp[:, nf:2 * nf]), lin(h, w_rp[:, 2 * nf:]), views)
+                h = F.relu(lin(agg, w_pp[:, nf:]) + pn + h)
         d = self.non_rigid_predictor
         x = h.reshape(B, N, nf)[:, :n_p].reshape(B * n_p, nf)
         if self.fused_dense:

@@ -253,6 +253,55 @@ class _Linear(torch.autograd.Function):
         return g @ W, out[0, : W.shape[0], : W.shape[1]], (out[0, : W.shape[0], W.shape[1]] if ctx.has_bias else None)
 
 
+class _Linear2(torch.autograd.Function):
+    """(x W1^T, x W2^T): the receiver / sender blocks of relation_propagator applied at node level.  One
+    backward for both: their weight gradients in ONE split-K call, the input gradient as two accumulating library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W1, W2):
+        ctx.save_for_backward(x, W1, W2)
+        return torch.nn.functional.linear(x, W1), torch.nn.functional.linear(x, W2)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, W1, W2 = ctx.saved_tensors
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        xs = x if x.stride(1) == 1 else x.contiguous()
+        out = weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0])
+        return torch.addmm(g1 @ W1, g2, W2), out[0, : W1.shape[0], : W1.shape[1]], out[1, : W2.shape[0], : W2.shape[1]]
+
+
+def linear2(x, W1, W2):
+    return _Linear2.apply(x, W1, W2)
+
+
+class _Add3Relu(torch.autograd.Function):
+    """relu(a + b + c) with one kernel each way (the three inputs share the gradient g * [y > 0])."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        y = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().ag_add3_relu(a.data_ptr(), b.data_ptr(), c.data_ptr(), y.data_ptr(), a.numel(), _stream_ptr(a.device)), "ag_add3_relu")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.lib().ag_relu_mask(g.data_ptr(), y.data_ptr(), out.data_ptr(), y.numel(), _stream_ptr(y.device)), "ag_relu_mask")
+        return out, out, out
+
+
+def add3_relu(a, b, c):
+    """relu((a + b) + c) for same-shape float tensors whose element count is a multiple of 4."""
+    return _Add3Relu.apply(a, b, c)
+
+
 def linear(x, W, b=None):
     """F.linear for (rows, <= 150) x (<= 150, <= 150) with rows >> 150 (see _Linear)."""
     return _Linear.apply(x, W, b)

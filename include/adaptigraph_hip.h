@@ -177,6 +177,11 @@ int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld
 int ag_train_chain(int kind, int backward, int precision, const float *x, const float *packed, float *const *y, const float *dy,
                    float *const *dz, float *dx, int64_t rows, int d_in, ag_stream_t stream);
 
+/* The node update's residual, Propagator.forward with res (model.py:36-40): y = relu((a + b) + c) over n contiguous floats
+ * (n % 4 == 0, 16-byte aligned), and its adjoint out = g * [y > 0] (the same for all three inputs). */
+int ag_add3_relu(const float *a, const float *b, const float *c, float *y, int64_t n, ag_stream_t stream);
+int ag_relu_mask(const float *g, const float *y, float *out, int64_t n, ag_stream_t stream);
+
 /* Weight and bias gradients of up to 4 dense layers in two launches: for layer l,
  *   out[l][o][k] = sum_rows dz[l][row][o] * prev[l][row][k]   (k < n_in[l])      = d loss / d W_l[o][k]
  *   out[l][o][n_in[l]] = sum_rows dz[l][row][o]                                   = d loss / d b_l[o]
