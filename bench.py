@@ -19,7 +19,8 @@ Prints one JSON line on rank 0 (contract in the task statement) with
                 `traffic` = HBM bytes per launch from the PMC passes recorded in profiles/pmc_traffic.json, used only
                 if that file was collected from the kernel sources being run (sha256 of adaptigraph_amd/csrc), else null
   roofline_hbm  the segment-reduce kernel (HBM-bound), same accounting against 8 TB/s
-  cpu_baseline  the CPU oracle ("port") on a bounded sample of the same workload on this box's cores (N = 1 only)
+  cpu_baseline  the CPU oracle ("port") on a bounded sample of the same workload on this box's cores (N = 1 only);
+                cpu_baseline_dense_bmm = the reference's dense one-hot-bmm formulation in PyTorch-CPU on a smaller sample
   extra         (N = 1 only) the exact-fp32 engine mode on the same workload, and BASELINE configs[2] / [3] per-GPU
                 shapes (granular-2k batch 128, cloth-4k batch 64 x 20 steps), each a short timed run of its own
   ranks         (N > 1) per-rank rollout / all-gather milliseconds per step (min / max over ranks)
@@ -104,6 +105,47 @@ def cpu_baseline(weights, material, n_obj, kw, seconds_budget=20.0):
     return {"value": bsz * steps * reps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
             "sample": f"{material} n_obj={n_obj}, batch {bsz}, {steps}-step rollout x {reps} reps ({dt:.1f} s), "
                       f"OpenMP over graphs, {cores} threads"}
+
+
+def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=12.0):
+    """the reference's FORMULATION on the host cores — dense one-hot Rr/Rs and `bmm` gathers in PyTorch-CPU
+    (oracle/torch_dense.py restates model.py:129-313), per step a radius-graph rebuild (the C oracle's O(N^2) builder, expanded
+    to one-hots as graph.py:152-155 returns them) + forward + state shift.  Bounded sample: the batch the one-hots let fit."""
+    from oracle import ag_oracle as ago
+    from oracle.torch_dense import dense_forward, one_hots
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mm = synth.MATERIALS[material]
+    bsz = 4 if n_obj <= 1000 else 1
+    g = synth.make_graph_inputs(material, n_obj, bsz, seed=0, **kw)
+    model = DynamicsPredictor.__new__(DynamicsPredictor)          # parameter containers only: no engine handle, nothing on a GPU
+    torch.nn.Module.__init__(model)
+    from adaptigraph_amd.model import _MLP3, _Lin, _Dec
+    model.particle_encoder, model.relation_encoder = _MLP3(6, 150, 150), _MLP3(17, 150, 150)
+    model.particle_propagator, model.relation_propagator, model.non_rigid_predictor = _Lin(300, 150), _Lin(450, 150), _Dec(150, 150, 3)
+    model._handle = None
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    state, attrs, action, p_inst, phys = (t(g[k]) for k in ("state", "attrs", "action", "p_instance", "phys"))
+    N, steps, reps = attrs.shape[1], 2, 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while True:
+            st = state.clone()
+            for _ in range(steps):
+                n_rel, recv, send = ago.build_edges(st[:, -1].numpy(), mm["radius"], g["mask"], g["tool_mask"], mm["topk"], mm["connect_tools_all"], "batch")
+                Rr, Rs = one_hots(n_rel, recv, send, N)
+                pos, _ = dense_forward(model, st, attrs, Rr, Rs, p_inst, action, phys)
+                cur = st[:, -1].clone()
+                cur[:, :pos.shape[1]] = pos
+                st = torch.cat([st[:, 1:], cur[:, None]], 1)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds_budget * 0.5:
+                break
+    return {"value": bsz * steps * reps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
+            "formulation": "dense one-hot Rr/Rs + bmm in PyTorch-CPU (the reference's formulation, model.py:129-313)",
+            "sample": f"{material} n_obj={n_obj}, batch {bsz}, {steps}-step rollout x {reps} reps ({dt:.1f} s), torch.set_num_threads({cores})"}
 
 
 class Engine:
@@ -293,6 +335,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"])
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            try:        # second baseline object: the reference's dense formulation (slower than the sparse port above, so the headline ratio stays conservative)
+                line["cpu_baseline_dense_bmm"] = cpu_baseline_dense(weights, args.material, wl["n_obj"], wl["kw"])
+            except Exception as e:      # noqa: BLE001 — a baseline leg must never lose the measured line
+                line["cpu_baseline_dense_bmm"] = {"error": repr(e)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

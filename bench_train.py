@@ -59,24 +59,9 @@ def synthetic_batch(B, n_obj_max, dev, seed=0):
 
 
 def dense_forward(model, state, attrs, Rr, Rs, p_instance, action, phys):
-    """The reference formulation (model.py:129-313): one-hot relation matrices and bmm."""
-    B, N = attrs.shape[:2]
-    n_p = p_instance.shape[1]
-    Rr_t = Rr.transpose(1, 2)
-    sn = torch.cat([state[:, 1:] - state[:, :-1], state[:, -1:]], 1).transpose(1, 2).reshape(B, N, -1)
-    ph = torch.cat([phys[:, None].expand(B, n_p, -1), phys.new_zeros(B, N - n_p, phys.shape[1])], 1)
-    p_in = torch.cat([attrs, ph, action], 2)
-    g = torch.cat([p_instance, p_instance.new_zeros(B, N - n_p, 1)], 1)
-    rel = torch.cat([Rr.bmm(attrs), Rs.bmm(attrs), (Rr.bmm(g) - Rs.bmm(g)).abs().sum(2, keepdim=True), Rr.bmm(sn) - Rs.bmm(sn)], 2)
-    mlp = lambda blk, x: F.relu(blk.model[4](F.relu(blk.model[2](F.relu(blk.model[0](x))))))
-    enc_n, enc_e = mlp(model.particle_encoder, p_in), mlp(model.relation_encoder, rel)
-    h = enc_n
-    for _ in range(model.model_config["pstep"]):
-        eff = F.relu(model.relation_propagator.linear(torch.cat([enc_e, Rr.bmm(h), Rs.bmm(h)], 2)))
-        h = F.relu(model.particle_propagator.linear(torch.cat([enc_n, Rr_t.bmm(eff)], 2)) + h)
-    d = model.non_rigid_predictor
-    m = d.linear_2(F.relu(d.linear_1(F.relu(d.linear_0(h[:, :n_p])))))
-    return state[:, -1, :n_p] + m.clamp(-100, 100)
+    """The reference formulation (model.py:129-313): one-hot relation matrices and bmm (oracle/torch_dense.py)."""
+    from oracle.torch_dense import dense_forward as f
+    return f(model, state, attrs, Rr, Rs, p_instance, action, phys)[0]
 
 
 def dense_unrolled_loss(model, data, Rr, Rs, n_future=3):

@@ -42,6 +42,27 @@ def test_forward(name, weights):
         assert np.abs(g["pred_motion"]).max() > 100 and np.abs(pos - g["state"][:, -1, :pos.shape[1]]).max() <= 100.0
 
 
+@pytest.mark.parametrize("name", ["fwd_rope301", "fwd_granular205", "fwd_cloth257"])
+def test_dense_bmm_baseline_formulation_matches_reference(name, weights):
+    """bench.py's second CPU baseline (oracle/torch_dense.py: one-hot Rr/Rs + bmm in PyTorch-CPU, the reference's formulation)
+    reproduces the reference forward on the golden inputs, so what it times is the reference's algorithm."""
+    import torch
+    from adaptigraph_amd.model import _Dec, _Lin, _MLP3
+    from oracle.torch_dense import dense_forward, one_hots
+    g = load_golden(name)
+    if float(g["decoder_scale"]) != 1.0:
+        pytest.skip("plain weights only")
+    m = torch.nn.Module()
+    m.particle_encoder, m.relation_encoder = _MLP3(6, 150, 150), _MLP3(17, 150, 150)
+    m.particle_propagator, m.relation_propagator, m.non_rigid_predictor = _Lin(300, 150), _Lin(450, 150), _Dec(150, 150, 3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Rr, Rs = one_hots(g["n_rel"], g["recv"], g["send"], g["attrs"].shape[1])
+    with torch.no_grad():
+        pos, mot = dense_forward(m, t(g["state"]), t(g["attrs"]), Rr, Rs, t(g["p_instance"]), t(g["action"]), t(g["phys"]))
+    assert np.abs(mot.numpy() - g["pred_motion"]).max() <= TOL and np.abs(pos.numpy() - g["pred_pos"]).max() <= TOL
+
+
 @pytest.mark.parametrize("name", golden_files("decode_action"))
 def test_decode_action(name):
     g = load_golden(name)
