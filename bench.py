@@ -21,8 +21,9 @@ Prints one JSON line on rank 0 (contract in the task statement) with
   roofline_hbm  the segment-reduce kernel (HBM-bound), same accounting against 8 TB/s
   cpu_baseline  the CPU oracle ("port") on a bounded sample of the same workload on this box's cores (N = 1 only);
                 cpu_baseline_dense_bmm = the reference's dense one-hot-bmm formulation in PyTorch-CPU on a smaller sample
-  extra         (N = 1 only) the exact-fp32 engine mode on the same workload, and BASELINE configs[2] / [3] per-GPU
-                shapes (granular-2k batch 128, cloth-4k batch 64 x 20 steps), each a short timed run of its own
+  extra         (N = 1 only) the exact-fp32 engine mode on the same workload, BASELINE configs[2] / [3] per-GPU shapes
+                (granular-2k batch 128, cloth-4k batch 64 x 20 steps) and configs[4] (one MPPI iteration, 1024 x 15 on
+                rope-1k), each a short timed run of its own
   ranks         (N > 1) per-rank rollout / all-gather milliseconds per step (min / max over ranks)
 """
 import argparse
@@ -329,6 +330,15 @@ def main():
                                        "precision": args.precision, "kernels": x["kernels"], "roofline": x["roofline"],
                                        "roofline_hbm": x["roofline_hbm"]}
             del e2
+
+        try:        # BASELINE configs[4] on one GPU: per-iteration wall-clock of the MPPI loop (bench_mpc.py measures it at N GPUs)
+            import bench_mpc
+            ms_it, _ = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision)
+            extra["mpc"] = {"workload": "MPPI iteration: 1024 sampled pushes x 15-step rollout on rope-1000, chamfer + penalty cost, softmax update "
+                                        "(BASELINE configs[4], 1 GPU)", "value": ms_it, "unit": "ms per iteration", "higher_is_better": False,
+                            "graph_steps_per_s": 1024 * 15 / ms_it * 1e3, "precision": args.precision}
+        except Exception as e:      # noqa: BLE001
+            extra["mpc"] = {"error": repr(e)}
 
     if rank == 0:
         wl = WORKLOADS[args.material]

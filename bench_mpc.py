@@ -31,6 +31,57 @@ from adaptigraph_amd import _lib, configs, losses, mpc, synth          # noqa: E
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
 
 
+def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1):
+    """Time `steps` MPPI iterations (sample -> sharded rollout -> chamfer/penalty cost -> softmax update) on this rank's GPU.
+    Returns (ms per iteration measured on this rank, last reward tensor)."""
+    import time
+    mat = "rope"
+    task = configs.task_config(mat)
+    # every sampled push is exactly push_steps long so an iteration is a fixed amount of work
+    lo = np.array(task["action_lower_lim"], np.float32)
+    hi = np.array(task["action_upper_lim"], np.float32)
+    lo[3], hi[3] = push_steps, push_steps + 0.5
+    state, act = synth.make_mpc_inputs(mat, particles, 1, seed=0, len_lo=push_steps, len_hi=push_steps + 0.4,
+                                       spacing=0.1 if particles >= 500 else 0.2)
+    target = (state + np.array([0.4, 0.0, 0.3], np.float32)).astype(np.float32)
+    bbox = np.array([[state[:, 0].min() - 5, state[:, 0].max() + 5], [state[:, 2].min() - 5, state[:, 2].max() + 5]])
+    g = torch.Generator().manual_seed(0)
+    model = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), dev)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
+    model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[precision])
+    ppm = configs.ppm_optimizer_stub(mat)
+    ppm.physics_param = {mat: torch.tensor([0.5], device=dev)}
+    state_t, target_t = torch.from_numpy(state).to(dev), torch.from_numpy(target).to(dev)
+    planner = mpc.MPPIPlanner(model, dev, ppm, partial(losses.chamfer, y=target_t[None]),
+                              partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
+                              n_sample=samples, n_update_iter=1, rollout_best=False)
+    act_seq = torch.from_numpy(act[0]).to(dev)
+
+    def one_iteration(seq, it):
+        torch.manual_seed(1234 + it)
+        smp = planner.sample(seq, 1)                      # iter_index > 0: perturb around the current sequence; broadcast from rank 0
+        new_seq, reward, _ = planner.step(state_t, smp)
+        return new_seq, reward
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    seq = act_seq
+    for i in range(warmup):
+        seq, _ = one_iteration(seq, i)
+    fence()
+    w0 = time.perf_counter()
+    for i in range(steps):
+        seq, reward = one_iteration(seq, warmup + i)
+    fence()
+    return (time.perf_counter() - w0) * 1e3 / steps, reward
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,58 +101,11 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     _lib.lib()
-
-    mat = "rope"
-    task = configs.task_config(mat)
-    # every sampled push is exactly --push-steps long so an iteration is a fixed amount of work
-    lo = np.array(task["action_lower_lim"], np.float32)
-    hi = np.array(task["action_upper_lim"], np.float32)
-    lo[3], hi[3] = a.push_steps, a.push_steps + 0.5
-    state, act = synth.make_mpc_inputs(mat, a.particles, 1, seed=0, len_lo=a.push_steps, len_hi=a.push_steps + 0.4,
-                                       spacing=0.1 if a.particles >= 500 else 0.2)
-    target = (state + np.array([0.4, 0.0, 0.3], np.float32)).astype(np.float32)
-    bbox = np.array([[state[:, 0].min() - 5, state[:, 0].max() + 5], [state[:, 2].min() - 5, state[:, 2].max() + 5]])
-    g = torch.Generator().manual_seed(0)
-    model = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), dev)
-    with torch.no_grad():
-        for p in model.parameters():
-            p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
-    model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[a.precision])
-    ppm = configs.ppm_optimizer_stub(mat)
-    ppm.physics_param = {mat: torch.tensor([0.5], device=dev)}
-    state_t, target_t = torch.from_numpy(state).to(dev), torch.from_numpy(target).to(dev)
-    planner = mpc.MPPIPlanner(model, dev, ppm, partial(losses.chamfer, y=target_t[None]),
-                              partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
-                              n_sample=a.samples, n_update_iter=1, rollout_best=False)
-    act_seq = torch.from_numpy(act[0]).to(dev)
-
-    def one_iteration(seq, it):
-        torch.manual_seed(1234 + it)                      # same samples on every rank (they are sharded by index)
-        samples = planner.sample(seq, 1)                  # iter_index > 0: perturb around the current sequence
-        new_seq, reward, _ = planner.step(state_t, samples)
-        return new_seq, reward
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    seq = act_seq
-    for i in range(a.warmup):
-        seq, _ = one_iteration(seq, i)
-    fence()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    import time
-    w0 = time.perf_counter()
-    for i in range(a.steps):
-        seq, reward = one_iteration(seq, a.warmup + i)
-    fence()
-    ms = (time.perf_counter() - w0) * 1e3
-    tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world)
+    tt = torch.tensor([per_it], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    ms = float(tt.item())
+    ms = float(tt.item()) * a.steps
     if rank == 0:
         per_it = ms / a.steps
         print(json.dumps({
