@@ -502,13 +502,27 @@ size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers)
 int ag_train_weight_grads(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
                           int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream)
 {
-    if (n_layers < 1 || n_layers > 4 || !dz || !dz_ld || !prev || !prev_ld || !n_in || !out || rows < 0) return fail(AG_ERR_ARG, "ag_train_weight_grads: bad argument");
-    for (int l = 0; l < n_layers; ++l)
+    return ag_train_weight_grads_into(n_layers, dz, dz_ld, prev, prev_ld, n_in, rows, out, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                                      stream);
+}
+
+int ag_train_weight_grads_into(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld,
+                               const int32_t *n_in, int64_t rows, float *out, float *const *w_grad, const int32_t *w_grad_ld, float *const *b_grad,
+                               const int32_t *n_out, void *workspace, size_t workspace_bytes, ag_stream_t stream)
+{
+    if (n_layers < 1 || n_layers > 4 || !dz || !dz_ld || !prev || !prev_ld || !n_in || rows < 0) return fail(AG_ERR_ARG, "ag_train_weight_grads: bad argument");
+    if (!w_grad && !out) return fail(AG_ERR_ARG, "ag_train_weight_grads: no destination");
+    for (int l = 0; l < n_layers; ++l) {
         if (!dz[l] || !prev[l] || n_in[l] < 1 || n_in[l] > AG_F || prev_ld[l] < n_in[l] || dz_ld[l] < 1 || dz_ld[l] > AG_FP)
             return fail(AG_ERR_ARG, "ag_train_weight_grads: layer %d: null table or n_in=%d ld=%d", l, n_in[l], prev_ld[l]);
+        if (w_grad && (!w_grad_ld || !n_out || (w_grad[l] && (n_out[l] < 1 || n_out[l] > AG_FP || w_grad_ld[l] < n_in[l]))))
+            return fail(AG_ERR_ARG, "ag_train_weight_grads_into: layer %d: bad destination", l);
+        if (w_grad && !w_grad[l] && !out) return fail(AG_ERR_ARG, "ag_train_weight_grads_into: layer %d has no destination", l);
+    }
     if (!workspace || workspace_bytes < ag_train_weight_grads_workspace_bytes(rows, n_layers))
         return fail(AG_ERR_WS, "ag_train_weight_grads: workspace %zu < %zu bytes", workspace_bytes, ag_train_weight_grads_workspace_bytes(rows, n_layers));
-    ag_launch_weight_grads(n_layers, dz, dz_ld, prev, prev_ld, n_in, rows, static_cast<float *>(workspace), out, static_cast<hipStream_t>(stream));
+    ag_launch_weight_grads(n_layers, dz, dz_ld, prev, prev_ld, n_in, rows, static_cast<float *>(workspace), out, w_grad, w_grad_ld, b_grad, n_out,
+                           static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
     return AG_OK;
 }

@@ -131,6 +131,7 @@ void ag_launch_add3_relu(const float *a, const float *b, const float *c, float *
 void ag_launch_relu_mask(const float *g, const float *y, float *out, long long n, hipStream_t s);
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers);
 void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_ld, const float *const *prev, const int *prev_ld, const int *n_in,
-                            long long rows, float *partial, float *out, hipStream_t s);
+                            long long rows, float *partial, float *out, float *const *w_dst, const int *w_ld, float *const *b_dst, const int *n_out,
+                            hipStream_t s);
 int ag_launch_chamfer(const float *x, const float *y, const unsigned char *xmask, const unsigned char *ymask, int B, int N, int M,
                       int y_batched, float *out, hipStream_t s);

@@ -85,6 +85,8 @@ struct DwArgs {
     int slab;                            // rows per workgroup
     float *partial;                      // [n_slabs][n_layers][160][160]
     float *out;                          // [n_layers][160][160]: out[l][o][k] = dW_l[o][k] (k < n_in), out[l][o][n_in] = db_l[o]
+    float *w_dst[4], *b_dst[4];          // optional: ACCUMULATE layer l's gradients straight into these (row stride w_ld) instead of `out`
+    int w_ld[4], n_out[4];
     int n_slabs, n_layers;
 };
 
@@ -180,7 +182,15 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwArgs a)
         float r = part[0][e];
 #pragma unroll
         for (int k = 1; k < 8; ++k) r += part[k][e];
-        a.out[(size_t)l * AG_FP * AG_FP + t] = r;
+        if (a.w_dst[l]) {            // accumulate into the parameter's .grad storage (each element has exactly one writer)
+            const int o = t / AG_FP, k = t - o * AG_FP;
+            if (o < a.n_out[l]) {
+                if (k < a.n_in[l]) a.w_dst[l][(size_t)o * a.w_ld[l] + k] += r;
+                else if (k == a.n_in[l] && a.b_dst[l]) a.b_dst[l][o] += r;
+            }
+        } else {
+            a.out[(size_t)l * AG_FP * AG_FP + t] = r;
+        }
     }
 }
 
@@ -237,10 +247,15 @@ size_t ag_weight_grads_ws_floats(long long rows, int n_layers)
     return (size_t)(slabs > 0 ? slabs : 1) * n_layers * AG_FP * AG_FP;
 }
 void ag_launch_weight_grads(int n_layers, const float *const *dz, const int *dz_ld, const float *const *prev, const int *prev_ld, const int *n_in,
-                            long long rows, float *partial, float *out, hipStream_t s)
+                            long long rows, float *partial, float *out, float *const *w_dst, const int *w_ld, float *const *b_dst, const int *n_out,
+                            hipStream_t s)
 {
     DwArgs a{};
-    for (int l = 0; l < n_layers; ++l) { a.dz[l] = dz[l]; a.dz_ld[l] = dz_ld[l]; a.prev[l] = prev[l]; a.prev_ld[l] = prev_ld[l]; a.n_in[l] = n_in[l]; }
+    for (int l = 0; l < n_layers; ++l) {
+        a.dz[l] = dz[l]; a.dz_ld[l] = dz_ld[l]; a.prev[l] = prev[l]; a.prev_ld[l] = prev_ld[l]; a.n_in[l] = n_in[l];
+        a.w_dst[l] = w_dst ? w_dst[l] : nullptr; a.b_dst[l] = (w_dst && b_dst) ? b_dst[l] : nullptr;
+        a.w_ld[l] = w_dst ? w_ld[l] : 0; a.n_out[l] = w_dst ? n_out[l] : 0;
+    }
     a.rows = rows; a.partial = partial; a.out = out; a.n_layers = n_layers;
     a.slab = dw_slab_rows(rows, n_layers);
     a.n_slabs = (int)((rows + a.slab - 1) / a.slab);

@@ -13,6 +13,8 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
+from . import train_ops
+
 from .dataset import DynDataset, attach_edges
 from .train_model import TrainableDynamicsPredictor, unrolled_loss
 
@@ -60,7 +62,8 @@ def train(config):
                 for i in range(n_iters):
                     data = attach_edges(next(loaders[ph]), dataset_config, device)
                     if ph == "train":
-                        optimizer.zero_grad()
+                        optimizer.zero_grad(set_to_none=False)      # the gradient kernel accumulates into the kept .grad buffers
+                    train_ops.DIRECT_GRADS = ph == "train" and getattr(model, "fused_dense", False)
                     loss = unrolled_loss(model, data, n_future)
                     if ph == "train":
                         loss.backward()

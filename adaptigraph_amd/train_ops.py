@@ -191,6 +191,7 @@ class _FusedChain(torch.autograd.Function):
                                            x.shape[1], _stream_ptr(dev))
         _lib.check(rc, "ag_train_chain(forward)")
         ctx.kind, ctx.rows, ctx.d_in, ctx.bwd, ctx.prec = kind, rows, x.shape[1], bwd, prec
+        ctx.params = list(layers) if DIRECT_GRADS else None
         ctx.shapes = [tuple(W.shape) for W, _ in layers]
         ctx.save_for_backward(xin, *ys)
         return ys[-1][:rows, : layers[-1][0].shape[0]]
@@ -211,27 +212,56 @@ class _FusedChain(torch.autograd.Function):
         _lib.check(rc, "ag_train_chain(backward)")
         # dW_l = dz_l^T y_{l-1}, db_l = column sums of dz_l: all layers in two launches (row-slab split-K on the fp32 MFMA,
         # fixed-order reduction) — a 150 x 150 output over 10^4..10^5 rows runs on 25 workgroups as a library GEMM
-        out = weight_grads(dzs, [xin] + ys[:-1], [s[1] for s in ctx.shapes], rows)
+        out = weight_grads(dzs, [xin] + ys[:-1], [s[1] for s in ctx.shapes], rows, ctx.params)
+        if out is None:
+            return (None, dx[:rows, : ctx.d_in]) + (None,) * (2 * n)
         grads = []
         for l, (n_out, n_in) in enumerate(ctx.shapes):
             grads += [out[l, :n_out, :n_in], out[l, :n_out, n_in]]
         return (None, dx[:rows, : ctx.d_in]) + tuple(grads)
 
 
-def weight_grads(dzs, prevs, n_ins, rows):
+DIRECT_GRADS = False    # True: weight / bias gradients are ACCUMULATED straight into the leaf parameters' .grad by the gradient kernel
+                        # and the autograd Functions return None for them (no per-parameter slice-backward / clone / add kernels:
+                        # ~200 of the ~620 launches of a training step).  Set by train.train() and bench_train.py; code that asks
+                        # autograd for parameter gradients (torch.autograd.grad) must leave it False.
+
+
+def _grad_slot(t):
+    """(pointer, row stride) of the .grad storage that corresponds to parameter tensor `t` — a leaf, or a column / row slice of
+    one (e.g. relation_propagator.linear.weight[:, :nf]); allocates a zero .grad on first use."""
+    base = t._base if t._base is not None else t
+    assert base.is_leaf and base.requires_grad and base.is_contiguous(), "DIRECT_GRADS needs leaf parameters (or plain slices of them)"
+    if base.grad is None:
+        base.grad = torch.zeros_like(base)
+    off = (t.data_ptr() - base.data_ptr()) // 4
+    return base.grad.data_ptr() + 4 * off, (base.grad.stride(0) if base.dim() == 2 else 0)
+
+
+def weight_grads(dzs, prevs, n_ins, rows, params=None):
     """[dz_l (rows+, ld <= 160)], [prev_l (rows+, ld)], [n_in_l] -> (n, 160, 160): out[l, o, k] = sum_rows dz_l[row, o] prev_l[row, k] for
-    k < n_in_l and out[l, o, n_in_l] = sum_rows dz_l[row, o]: weight and bias gradients of up to 4 layers in two launches."""
+    k < n_in_l and out[l, o, n_in_l] = sum_rows dz_l[row, o]: weight and bias gradients of up to 4 layers in two launches.
+    With `params` = [(W_l, b_l or None)] (DIRECT_GRADS) the sums are accumulated into W_l.grad / b_l.grad instead and None is returned."""
     n, dev = len(dzs), dzs[0].device
     assert 1 <= n <= 4 and all(t.stride(1) == 1 for t in list(dzs) + list(prevs))
-    out = torch.empty((n, AG_FP, AG_FP), dtype=torch.float32, device=dev)
     L = _lib.lib()
     ws = workspace(dev, L.ag_train_weight_grads_workspace_bytes(rows, n))
     i32 = lambda v: (ctypes.c_int32 * 4)(*(list(v) + [0] * (4 - n)))
+    if params is None:
+        out = torch.empty((n, AG_FP, AG_FP), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.ag_train_weight_grads(n, _ptr_array(dzs), i32(t.stride(0) for t in dzs), _ptr_array(prevs), i32(t.stride(0) for t in prevs),
+                                         i32(n_ins), rows, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+        _lib.check(rc, "ag_train_weight_grads")
+        return out
+    slots = [(_grad_slot(W), _grad_slot(b)[0] if b is not None else None, W.shape[0]) for W, b in params]
+    pv = lambda v: (ctypes.c_void_p * 4)(*(list(v) + [None] * (4 - n)))
     with torch.cuda.device(dev):
-        rc = L.ag_train_weight_grads(n, _ptr_array(dzs), i32(t.stride(0) for t in dzs), _ptr_array(prevs), i32(t.stride(0) for t in prevs),
-                                     i32(n_ins), rows, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
-    _lib.check(rc, "ag_train_weight_grads")
-    return out
+        rc = L.ag_train_weight_grads_into(n, _ptr_array(dzs), i32(t.stride(0) for t in dzs), _ptr_array(prevs), i32(t.stride(0) for t in prevs),
+                                          i32(n_ins), rows, None, pv(s[0][0] for s in slots), i32(s[0][1] for s in slots), pv(s[1] for s in slots),
+                                          i32(s[2] for s in slots), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "ag_train_weight_grads_into")
+    return None
 
 
 class _Linear(torch.autograd.Function):
@@ -241,6 +271,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
+        ctx.params = [(W, b)] if DIRECT_GRADS else None
         ctx.has_bias = b is not None
         return torch.nn.functional.linear(x, W, b)
 
@@ -249,7 +280,9 @@ class _Linear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         g = g.contiguous()
         xs = x if x.stride(1) == 1 else x.contiguous()
-        out = weight_grads([g], [xs], [W.shape[1]], x.shape[0])
+        out = weight_grads([g], [xs], [W.shape[1]], x.shape[0], ctx.params)
+        if out is None:
+            return g @ W, None, None
         return g @ W, out[0, : W.shape[0], : W.shape[1]], (out[0, : W.shape[0], W.shape[1]] if ctx.has_bias else None)
 
 
@@ -260,6 +293,7 @@ class _Linear2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, W2):
         ctx.save_for_backward(x, W1, W2)
+        ctx.params = [(W1, None), (W2, None)] if DIRECT_GRADS else None
         return torch.nn.functional.linear(x, W1), torch.nn.functional.linear(x, W2)
 
     @staticmethod
@@ -267,8 +301,11 @@ class _Linear2(torch.autograd.Function):
         x, W1, W2 = ctx.saved_tensors
         g1, g2 = g1.contiguous(), g2.contiguous()
         xs = x if x.stride(1) == 1 else x.contiguous()
-        out = weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0])
-        return torch.addmm(g1 @ W1, g2, W2), out[0, : W1.shape[0], : W1.shape[1]], out[1, : W2.shape[0], : W2.shape[1]]
+        out = weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0], ctx.params)
+        dx = torch.addmm(g1 @ W1, g2, W2)
+        if out is None:
+            return dx, None, None
+        return dx, out[0, : W1.shape[0], : W1.shape[1]], out[1, : W2.shape[0], : W2.shape[1]]
 
 
 def linear2(x, W1, W2):

@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--dense-baseline", action="store_true")
     ap.add_argument("--library-gemm", action="store_true", help="dense stacks through torch F.linear (the r01 path) instead of the fused MFMA chains")
     ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step in a HIP graph (torch.cuda.graphs) and replay it")
+    ap.add_argument("--autograd-grads", action="store_true", help="parameter gradients through autograd's accumulation instead of straight into .grad")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs an MI355X: the graph kernels have no CPU path")
@@ -103,12 +104,14 @@ def main():
     torch.manual_seed(0)
     model = TrainableDynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), dev).to(dev).train()
     model.fused_dense = not a.library_gemm
+    from adaptigraph_amd import train_ops
+    train_ops.DIRECT_GRADS = model.fused_dense and not a.autograd_grads
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=a.graph)
     data, csr = synthetic_batch(a.batch, a.max_nobj, dev)
     data.update(Rr=csr, Rs=None, edge_views=EdgeViews(csr))
 
     def step():
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=False)     # keep the .grad buffers: the gradient kernel accumulates into them
         loss = unrolled_loss(model, data, 3)
         loss.backward()
         opt.step()
@@ -128,6 +131,7 @@ def main():
         g = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=False)
         with torch.cuda.graph(g):
+            opt.zero_grad(set_to_none=False)              # inside the graph: every replay starts from zero gradients
             static_loss = unrolled_loss(model, data, 3)
             static_loss.backward()
             opt.step()
@@ -142,7 +146,7 @@ def main():
             "config": {"workload": f"rope key-point graphs, batch {a.batch}, <= {a.max_nobj}+1 nodes, {int(csr.n_rel().sum())} edges in the batch"},
             "graphs_per_s": round(a.batch / ms * 1e3, 1),
             "dense_stacks": "library GEMMs (F.linear)" if a.library_gemm else "fused fp32-MFMA chain kernels (forward + backward)",
-            "hip_graph": bool(a.graph)}
+            "hip_graph": bool(a.graph), "direct_grads": bool(train_ops.DIRECT_GRADS)}
     if a.dense_baseline:
         Rr, Rs = csr.to_dense(torch.float32)
         model.load_state_dict(init)

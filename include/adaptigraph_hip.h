@@ -192,6 +192,14 @@ size_t ag_train_weight_grads_workspace_bytes(int64_t rows, int n_layers);
 int ag_train_weight_grads(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld, const int32_t *n_in,
                           int64_t rows, float *out, void *workspace, size_t workspace_bytes, ag_stream_t stream);
 
+/* The same, ACCUMULATING layer l's gradients straight into caller storage (a parameter's .grad): w_grad[l][o * w_grad_ld[l] + k] +=
+ * dW_l[o][k] for o < n_out[l], k < n_in[l], and b_grad[l][o] += db_l[o] (b_grad or b_grad[l] may be NULL).  A layer whose w_grad[l]
+ * is NULL goes to `out` as above.  This is what removes autograd's per-parameter slice / clone / accumulate kernels from the
+ * training step (train.py:110-112 loss.backward() accumulates into .grad the same way). */
+int ag_train_weight_grads_into(int n_layers, const float *const *dz, const int32_t *dz_ld, const float *const *prev, const int32_t *prev_ld,
+                               const int32_t *n_in, int64_t rows, float *out, float *const *w_grad, const int32_t *w_grad_ld, float *const *b_grad,
+                               const int32_t *n_out, void *workspace, size_t workspace_bytes, ag_stream_t stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around every launch of each
  * kernel class (used by bench.py for the roofline line; off by default, costs two event records per launch).
  * ag_profile_read synchronises on the recorded events and returns, per class, the summed milliseconds, the

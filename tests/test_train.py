@@ -191,6 +191,29 @@ def test_unrolled_loss_and_gradients_match_reference(weights):
 
 
 @pytest.mark.gpu
+def test_direct_gradient_accumulation_equals_autograd(weights, monkeypatch):
+    """train_ops.DIRECT_GRADS: the weight-gradient kernel accumulates straight into the leaf parameters' .grad (through the
+    column slices of relation_propagator / particle_propagator too) and autograd sees None — the result must equal what
+    autograd's own accumulation produces, over two backward passes (accumulation) of the 3-step unrolled loss."""
+    from adaptigraph_amd import train_ops
+    from adaptigraph_amd.train_model import unrolled_loss
+    g = load_golden("train_rope")
+    data = {k: tg(v) for k, v in batch_from(g).items()}
+    data.update(Rr=golden_csr(g, g["b_attrs"].shape[1]), Rs=None)
+    grads = {}
+    for direct in (False, True):
+        monkeypatch.setattr(train_ops, "DIRECT_GRADS", direct)
+        model = trainable(weights).train()
+        for _ in range(2):
+            unrolled_loss(model, data, 3).backward()
+        grads[direct] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for n, ref in grads[False].items():
+        assert (grads[True][n] - ref).abs().max().item() <= 1e-6 * max(1e-6, ref.abs().max().item()), n
+    ref1 = g["grad_particle_encoder.model.0.weight"]
+    assert np.abs(grads[True]["particle_encoder.model.0.weight"].cpu().numpy() - 2 * ref1).max() <= 4e-4 * np.abs(ref1).max()
+
+
+@pytest.mark.gpu
 def test_trainable_forward_equals_fused_engine(weights):
     """Same weights, same graph: the autograd forward and the fused inference engine (exact-fp32 mode) agree."""
     from adaptigraph_amd.model import DynamicsPredictor
