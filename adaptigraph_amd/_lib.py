@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = ("ag_last_error", "ag_version", "ag_model_create", "ag_model_update_weights", "ag_model_destroy",
            "ag_edge_capacity", "ag_edges_workspace_bytes", "ag_build_edges", "ag_forward_workspace_bytes",
            "ag_forward", "ag_rollout_workspace_bytes", "ag_rollout", "ag_profile_enable", "ag_profile_read", "ag_set_option", "ag_chamfer", "ag_chamfer_masked", "ag_gather_rows", "ag_segment_sum",
-           "ag_message_forward", "ag_message_backward", "ag_model_status", "ag_train_pack", "ag_train_chain", "ag_train_weight_grads", "ag_train_weight_grads_workspace_bytes", "ag_add3_relu", "ag_relu_mask", "ag_train_weight_grads_into")
+           "ag_message_forward", "ag_message_backward", "ag_model_status", "ag_train_pack", "ag_train_chain", "ag_train_weight_grads", "ag_train_weight_grads_workspace_bytes", "ag_add3_relu", "ag_relu_mask", "ag_train_weight_grads_into", "ag_edge_inputs_forward", "ag_edge_inputs_backward")
 KERNEL_CLASSES = ("build_edges", "node_encode", "edge_encode", "aggregate", "node_update", "rollout_step")
 
 AG_VARIANT_SINGLE, AG_VARIANT_BATCH = 0, 1
@@ -116,6 +116,10 @@ def lib():
                                              ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, c_void_p,
                                              ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_void_p),
                                              ctypes.POINTER(ctypes.c_int32), c_void_p, c_size_t, c_void_p]
+    L.ag_edge_inputs_forward.restype = c_int
+    L.ag_edge_inputs_forward.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p]
+    L.ag_edge_inputs_backward.restype = c_int
+    L.ag_edge_inputs_backward.argtypes = [c_void_p, c_int, c_int, c_int] + [c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int64, c_void_p]
     L.ag_add3_relu.restype = c_int
     L.ag_add3_relu.argtypes = [c_void_p] * 4 + [ctypes.c_int64, c_void_p]
     L.ag_relu_mask.restype = c_int

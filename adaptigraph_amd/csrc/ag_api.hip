@@ -478,6 +478,29 @@ int ag_train_chain(int kind, int backward, int precision, const float *x, const 
     return AG_OK;
 }
 
+int ag_edge_inputs_forward(const float *tab, int D, int attr_dim, int group_dim, const int32_t *recv, const int32_t *send, float *out, int64_t n_edges,
+                           ag_stream_t stream)
+{
+    if (D < 1 || attr_dim < 0 || group_dim < 0 || attr_dim + group_dim > D || n_edges < 0) return fail(AG_ERR_ARG, "ag_edge_inputs_forward: bad sizes");
+    if (n_edges > 0 && (!tab || !recv || !send || !out)) return fail(AG_ERR_ARG, "ag_edge_inputs_forward: null argument");
+    ag_launch_edge_inputs_fwd(tab, D, attr_dim, group_dim, recv, send, out, n_edges, static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_edge_inputs_backward(const float *tab, int D, int attr_dim, int group_dim, const int32_t *recv, const int32_t *send, const int32_t *row_ptr,
+                            const int32_t *col_ptr, const int32_t *send_perm, const float *grad_out, float *scratch_r, float *scratch_s, float *grad_tab,
+                            int64_t n_edges, int64_t n_nodes, ag_stream_t stream)
+{
+    if (D < 1 || attr_dim < 0 || group_dim < 0 || attr_dim + group_dim > D || n_edges < 0 || n_nodes < 0) return fail(AG_ERR_ARG, "ag_edge_inputs_backward: bad sizes");
+    if (n_nodes > 0 && (!row_ptr || !col_ptr || !grad_tab)) return fail(AG_ERR_ARG, "ag_edge_inputs_backward: null argument");
+    if (n_edges > 0 && (!tab || !recv || !send || !send_perm || !grad_out || !scratch_r || !scratch_s)) return fail(AG_ERR_ARG, "ag_edge_inputs_backward: null argument");
+    ag_launch_edge_inputs_bwd(tab, D, attr_dim, group_dim, recv, send, row_ptr, col_ptr, send_perm, grad_out, scratch_r, scratch_s, grad_tab, n_edges, n_nodes,
+                              static_cast<hipStream_t>(stream));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_add3_relu(const float *a, const float *b, const float *c, float *y, int64_t n, ag_stream_t stream)
 {
     if (n < 0 || (n & 3) || (n > 0 && (!a || !b || !c || !y))) return fail(AG_ERR_ARG, "ag_add3_relu: n=%lld must be a non-negative multiple of 4, tensors non-null", (long long)n);

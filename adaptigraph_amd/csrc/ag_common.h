@@ -127,6 +127,9 @@ struct AgChainArgsPOD { const float *x; const float *w; float *y[4]; const float
 void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld, int col0, int transposed, int compact,
                           int n_tiles, int b3, float *dst, hipStream_t s);
 void ag_launch_chain(int kind, int backward, int b3, const AgChainArgsPOD &p, int max_blocks, hipStream_t s);
+void ag_launch_edge_inputs_fwd(const float *tab, int D, int A, int G, const int *recv, const int *send, float *out, long long E, hipStream_t s);
+void ag_launch_edge_inputs_bwd(const float *tab, int D, int A, int G, const int *recv, const int *send, const int *row_ptr, const int *col_ptr,
+                               const int *perm, const float *gout, float *g_r, float *g_s, float *gtab, long long E, long long M, hipStream_t s);
 void ag_launch_add3_relu(const float *a, const float *b, const float *c, float *y, long long n, hipStream_t s);
 void ag_launch_relu_mask(const float *g, const float *y, float *out, long long n, hipStream_t s);
 size_t ag_weight_grads_ws_floats(long long rows, int n_layers);

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .graph import CSREdges, csr_from_dense
 from .model import DynamicsPredictor
-from .train_ops import EdgeViews, add3_relu, fused_chain, gather_receivers, gather_senders, linear, linear2, message_sum
+from .train_ops import EdgeViews, add3_relu, edge_inputs, fused_chain, gather_receivers, gather_senders, linear, linear2, message_sum
 
 
 def _mlp3(block, x):
@@ -48,10 +48,13 @@ class TrainableDynamicsPredictor(DynamicsPredictor):
 
         # edge inputs [attrs_r | attrs_s | sum|g_r - g_s| | state_norm_r - state_norm_s]  (:220-253): one gather per side
         node_tab = torch.cat([attrs.reshape(M, -1), group, state_norm], 1)
-        tab_r, tab_s = gather_receivers(node_tab, views), gather_senders(node_tab, views)
         a, g = attrs.shape[2], n_inst
-        rel_inputs = torch.cat([tab_r[:, :a], tab_s[:, :a], (tab_r[:, a:a + g] - tab_s[:, a:a + g]).abs().sum(1, keepdim=True),
-                                tab_r[:, a + g:] - tab_s[:, a + g:]], 1)
+        if self.fused_dense:
+            rel_inputs = edge_inputs(node_tab, views, a, g)
+        else:
+            tab_r, tab_s = gather_receivers(node_tab, views), gather_senders(node_tab, views)
+            rel_inputs = torch.cat([tab_r[:, :a], tab_s[:, :a], (tab_r[:, a:a + g] - tab_s[:, a:a + g]).abs().sum(1, keepdim=True),
+                                    tab_r[:, a + g:] - tab_s[:, a + g:]], 1)
 
         w_rp, b_rp = self.relation_propagator.linear.weight, self.relation_propagator.linear.bias
         w_pp, b_pp = self.particle_propagator.linear.weight, self.particle_propagator.linear.bias

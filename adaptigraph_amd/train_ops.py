@@ -99,6 +99,43 @@ def gather_senders(x, views):
     return _GatherRows.apply(x, views.send, views.col_ptr, views.send_perm)
 
 
+class _EdgeInputs(torch.autograd.Function):
+    """rel_inputs (model.py:220-253) from the per-node table [attrs | group | state_norm] in one kernel; backward in two."""
+
+    @staticmethod
+    def forward(ctx, tab, views, attr_dim, group_dim):
+        _require_gpu(tab, "tab")
+        tab = tab.contiguous().float()
+        D = tab.shape[1]
+        out = torch.empty((views.E, 2 * attr_dim + 1 + (D - attr_dim - group_dim)), dtype=torch.float32, device=tab.device)
+        with torch.cuda.device(tab.device):
+            rc = _lib.lib().ag_edge_inputs_forward(tab.data_ptr(), D, attr_dim, group_dim, views.recv.data_ptr(), views.send.data_ptr(),
+                                                   out.data_ptr(), views.E, _stream_ptr(tab.device))
+        _lib.check(rc, "ag_edge_inputs_forward")
+        ctx.save_for_backward(tab)
+        ctx.meta = (views, attr_dim, group_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (tab,) = ctx.saved_tensors
+        v, a, gdim = ctx.meta
+        g = g.contiguous()
+        scratch = torch.empty((2, max(v.E, 1), tab.shape[1]), dtype=torch.float32, device=tab.device)
+        gtab = torch.empty_like(tab)
+        with torch.cuda.device(tab.device):
+            rc = _lib.lib().ag_edge_inputs_backward(tab.data_ptr(), tab.shape[1], a, gdim, v.recv.data_ptr(), v.send.data_ptr(), v.row_ptr.data_ptr(),
+                                                    v.col_ptr.data_ptr(), v.send_perm.data_ptr(), g.data_ptr(), scratch[0].data_ptr(),
+                                                    scratch[1].data_ptr(), gtab.data_ptr(), v.E, tab.shape[0], _stream_ptr(tab.device))
+        _lib.check(rc, "ag_edge_inputs_backward")
+        return gtab, None, None, None
+
+
+def edge_inputs(tab, views, attr_dim, group_dim):
+    """tab (M, A + G + S) = [attrs | group | state_norm] -> rel_inputs (E, 2A + 1 + S) as DynamicsPredictor.forward builds them."""
+    return _EdgeInputs.apply(tab, views, attr_dim, group_dim)
+
+
 def message_sum(eterm, hr, hs, views):
     """(E,D), (M,D), (M,D) -> (M,D): sum over each receiver's edges of relu(eterm[e] + hr[recv] + hs[send])."""
     if views.E == 0:      # a batch without edges (the reference's dense bmm handles it: model.py:295 on an empty Rr)

@@ -177,6 +177,17 @@ int ag_train_pack(const float *W, const float *bias, int n_out, int n_in, int ld
 int ag_train_chain(int kind, int backward, int precision, const float *x, const float *packed, float *const *y, const float *dy,
                    float *const *dz, float *dx, int64_t rows, int d_in, ag_stream_t stream);
 
+/* rel_inputs of DynamicsPredictor.forward (model.py:220-253) and its adjoint, from one per-node table
+ *   tab (n_nodes, D) = [attrs (attr_dim) | group = cat(p_instance, 0) (group_dim) | state_norm (D - attr_dim - group_dim)]:
+ *   out[e] = [tab[r][:A] | tab[s][:A] | sum |tab[r][A:A+G] - tab[s][A:A+G]| | tab[r][A+G:] - tab[s][A+G:]], width 2A + 1 + (D - A - G),
+ * with r = recv[e], s = send[e] (global node ids).  Backward: grad_tab[n] = sum over the edges n receives (row_ptr order) and
+ * sends (col_ptr / send_perm order) of the per-edge gradients; scratch_r / scratch_s are (n_edges, D) each. */
+int ag_edge_inputs_forward(const float *tab, int D, int attr_dim, int group_dim, const int32_t *recv, const int32_t *send, float *out, int64_t n_edges,
+                           ag_stream_t stream);
+int ag_edge_inputs_backward(const float *tab, int D, int attr_dim, int group_dim, const int32_t *recv, const int32_t *send, const int32_t *row_ptr,
+                            const int32_t *col_ptr, const int32_t *send_perm, const float *grad_out, float *scratch_r, float *scratch_s, float *grad_tab,
+                            int64_t n_edges, int64_t n_nodes, ag_stream_t stream);
+
 /* The node update's residual, Propagator.forward with res (model.py:36-40): y = relu((a + b) + c) over n contiguous floats
  * (n % 4 == 0, 16-byte aligned), and its adjoint out = g * [y > 0] (the same for all three inputs). */
 int ag_add3_relu(const float *a, const float *b, const float *c, float *y, int64_t n, ag_stream_t stream);
