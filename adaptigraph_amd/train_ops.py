@@ -301,6 +301,47 @@ def weight_grads(dzs, prevs, n_ins, rows, params=None):
     return None
 
 
+# Deferred weight gradients (DIRECT_GRADS only).  The node-level linears of the three propagation rounds each need a (150 x 150)
+# gradient over the same ~10^4 rows; one call per layer is latency-bound (24-66 us for 5 us of MFMA time).  Nothing reads a
+# parameter's .grad before backward() returns, so their (dz, input) pairs are queued and computed four layers per launch —
+# when a group fills up and, for the remainder, from a callback the autograd engine runs at the end of the backward pass.
+_PENDING, _PENDING_ARMED = [], [False]
+
+
+def _flush_pending(final=True):
+    by_rows = {}
+    for item in _PENDING:
+        by_rows.setdefault((item[3], item[0].device), []).append(item)
+    _PENDING.clear()
+    for (rows, _), items in by_rows.items():
+        while items and (final or len(items) >= 8):
+            # up to four layers per launch, each with its OWN destination: two layers of one launch accumulating into the same
+            # parameter (the same weight in two propagation rounds) would race on its .grad
+            grp, rest, seen = [], [], set()
+            for it in items:
+                key = it[4][0].data_ptr()
+                if len(grp) < 4 and key not in seen:
+                    grp.append(it)
+                    seen.add(key)
+                else:
+                    rest.append(it)
+            items = rest
+            weight_grads([i[0] for i in grp], [i[1] for i in grp], [i[2] for i in grp], rows, [i[4] for i in grp])
+        _PENDING.extend(items)
+    if final:
+        _PENDING_ARMED[0] = False
+
+
+def _defer_weight_grads(dz, prev, n_in, rows, params):
+    """Queue layers [(dz, prev, n_in, (W, b))] sharing `rows`; call only from inside a backward pass."""
+    for z, p, k, wb in zip(dz, prev, n_in, params):
+        _PENDING.append((z, p, k, rows, wb))
+    if not _PENDING_ARMED[0]:
+        _PENDING_ARMED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+    _flush_pending(final=False)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b) as a library GEMM, with the weight / bias gradient on the split-K MFMA kernel: for the node-level
     linears (150 x 150 outputs contracted over ~10^4 rows) hipBLASLt picks a 25-workgroup kernel (75 us per call)."""
@@ -317,9 +358,10 @@ class _Linear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         g = g.contiguous()
         xs = x if x.stride(1) == 1 else x.contiguous()
-        out = weight_grads([g], [xs], [W.shape[1]], x.shape[0], ctx.params)
-        if out is None:
+        if ctx.params is not None:
+            _defer_weight_grads([g], [xs], [W.shape[1]], x.shape[0], ctx.params)
             return g @ W, None, None
+        out = weight_grads([g], [xs], [W.shape[1]], x.shape[0])
         return g @ W, out[0, : W.shape[0], : W.shape[1]], (out[0, : W.shape[0], W.shape[1]] if ctx.has_bias else None)
 
 
@@ -338,10 +380,11 @@ class _Linear2(torch.autograd.Function):
         x, W1, W2 = ctx.saved_tensors
         g1, g2 = g1.contiguous(), g2.contiguous()
         xs = x if x.stride(1) == 1 else x.contiguous()
-        out = weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0], ctx.params)
         dx = torch.addmm(g1 @ W1, g2, W2)
-        if out is None:
+        if ctx.params is not None:
+            _defer_weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0], ctx.params)
             return dx, None, None
+        out = weight_grads([g1, g2], [xs, xs], [W1.shape[1], W2.shape[1]], x.shape[0])
         return dx, out[0, : W1.shape[0], : W1.shape[1]], out[1, : W2.shape[0], : W2.shape[1]]
 
 
