@@ -63,10 +63,16 @@ def train(config):
                     data = attach_edges(next(loaders[ph]), dataset_config, device)
                     if ph == "train":
                         optimizer.zero_grad(set_to_none=False)      # the gradient kernel accumulates into the kept .grad buffers
+                    # parameter gradients straight into .grad for this forward + backward only (train_ops.DIRECT_GRADS is a
+                    # process-wide switch: code that asks autograd for parameter gradients must find it off)
                     train_ops.DIRECT_GRADS = ph == "train" and getattr(model, "fused_dense", False)
-                    loss = unrolled_loss(model, data, n_future)
+                    try:
+                        loss = unrolled_loss(model, data, n_future)
+                        if ph == "train":
+                            loss.backward()
+                    finally:
+                        train_ops.DIRECT_GRADS = False
                     if ph == "train":
-                        loss.backward()
                         optimizer.step()
                         if i % train_config["log_interval"] == 0:
                             logged.append(loss.item())
