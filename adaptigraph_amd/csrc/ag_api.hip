@@ -470,9 +470,15 @@ int ag_train_chain(int kind, int backward, int precision, const float *x, const 
         p.dz[l] = backward ? dz[l] : nullptr;
     }
     if (rows == 0) return AG_OK;
+    static int cus_of[64];      // CU count per device, queried once (hipGetDeviceProperties is far too slow for a per-launch call)
     int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cus_of[dev] == 0) {
+            hipDeviceProp_t prop;
+            cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        cus = cus_of[dev];
+    }
     ag_launch_chain(kind, backward ? 1 : 0, precision ? 1 : 0, p, AG_MLP_WG_PER_CU * cus, static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
     return AG_OK;

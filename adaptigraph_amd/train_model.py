@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .graph import CSREdges, csr_from_dense
 from .model import DynamicsPredictor
-from .train_ops import EdgeViews, add3_relu, edge_inputs, fused_chain, gather_receivers, gather_senders, linear, linear2, message_sum
+from .train_ops import EdgeViews, add3_relu, edge_inputs, fused_chain, gather_receivers, gather_senders, linear, linear2, message_sum, reset_pending
 
 
 def _mlp3(block, x):
@@ -96,6 +96,7 @@ def unrolled_loss(model, data, n_future, loss_funcs=None):
     `data` is the collated batch dict; it is not modified.  -> scalar loss."""
     if loss_funcs is None:
         loss_funcs = [(F.mse_loss, 1)]
+    reset_pending()
     data = dict(data)
     if "edge_views" not in data:
         Rr, Rs = data["Rr"], data.get("Rs")

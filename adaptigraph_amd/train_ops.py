@@ -332,6 +332,12 @@ def _flush_pending(final=True):
         _PENDING_ARMED[0] = False
 
 
+def reset_pending():
+    """Drop queued weight-gradient work (a backward pass that raised leaves its queue behind; unrolled_loss calls this)."""
+    _PENDING.clear()
+    _PENDING_ARMED[0] = False
+
+
 def _defer_weight_grads(dz, prev, n_in, rows, params):
     """Queue layers [(dz, prev, n_in, (W, b))] sharing `rows`; call only from inside a backward pass."""
     for z, p, k, wb in zip(dz, prev, n_in, params):

@@ -118,12 +118,10 @@ def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=12.0):
     mm = synth.MATERIALS[material]
     bsz = 4 if n_obj <= 1000 else 1
     g = synth.make_graph_inputs(material, n_obj, bsz, seed=0, **kw)
-    model = DynamicsPredictor.__new__(DynamicsPredictor)          # parameter containers only: no engine handle, nothing on a GPU
-    torch.nn.Module.__init__(model)
     from adaptigraph_amd.model import _MLP3, _Lin, _Dec
+    model = torch.nn.Module()                                     # the reference's parameter containers only: nothing of the engine, nothing on a GPU
     model.particle_encoder, model.relation_encoder = _MLP3(6, 150, 150), _MLP3(17, 150, 150)
     model.particle_propagator, model.relation_propagator, model.non_rigid_predictor = _Lin(300, 150), _Lin(450, 150), _Dec(150, 150, 3)
-    model._handle = None
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     state, attrs, action, p_inst, phys = (t(g[k]) for k in ("state", "attrs", "action", "p_instance", "phys"))
