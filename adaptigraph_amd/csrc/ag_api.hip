@@ -563,7 +563,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
-    else if (!strcmp(name, "edge_rows")) m->edge_rows = value == 32 ? 32 : 64;
+    else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }

@@ -73,7 +73,7 @@ struct AgFwdArgs {
     int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
     int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced (ag_model_status)
     int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
-                       // per wave, one 512-register workgroup per CU (edge_encode64_kernel)
+                       // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };
 #define AG_TILE_CTRS 4
 

@@ -342,8 +342,9 @@ struct Ring4 {
     const float4 *g;   // weight stream (global), walked cyclically
     int total;         // chunks in the stream
     int fetch;         // next stream chunk to copy
-    int buf;           // ring buffer holding the chunk being consumed (0..3)
-    float *lds;        // 4 * AG_CHUNK_FLOATS
+    int buf;           // ring buffer holding the chunk being consumed (0..depth-1)
+    int depth;         // 4 (one workgroup per CU) or 3 (two per CU: 60 KB each; copies issued at the START of a tile, drained at its end)
+    float *lds;        // depth * AG_CHUNK_FLOATS
     bf16x8 wq[4][2];   // [slot][hi|lo]
 #if AG_TRACE
     int tr = -1, trb = 0;
@@ -362,26 +363,37 @@ __device__ __forceinline__ unsigned ring_cur(const Ring4 &R, int lane)
 }
 __device__ __forceinline__ unsigned ring_next(const Ring4 &R, int lane)
 {
-    return lds_addr_of(R.lds) + (unsigned)(((R.buf + 1) & 3) * AG_CHUNK_FLOATS * 4 + lane * 16);
+    const int nb = R.buf + 1 == R.depth ? 0 : R.buf + 1;
+    return lds_addr_of(R.lds) + (unsigned)(nb * AG_CHUNK_FLOATS * 4 + lane * 16);
 }
-// one 1 KB-per-wave piece (of five) of chunk `fetch` -> buffer (buf + 3) % 4
+// one 1 KB-per-wave piece (of five) of chunk `fetch` -> buffer (buf + depth - 1) % depth
 __device__ __forceinline__ void ring_dma_piece(Ring4 &R, int piece)
 {
     int f = R.fetch;
     asm volatile("" : "+s"(f));     // keep the (cyclic) chunk address out of LICM's reach, as pipe_dma does
     const float4 *g = R.g + (size_t)f * AG_CHUNK_F4 + threadIdx.x + 256 * piece;
-    const int tb = (R.buf + 3) & 3;
+    const int tb = R.buf == 0 ? R.depth - 1 : R.buf - 1;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)R.lds;
     const unsigned dst = __builtin_amdgcn_readfirstlane(base + (tb * AG_CHUNK_FLOATS + (threadIdx.x >> 6) * 256) * 4) + 16 * 256 * piece;
     dma16(g, dst);
 }
-// k16-step S (of 10) of a chunk: mid-tile, drain the copies issued during the previous tile, then issue this tile's
+// k16-step S (of 10) of a chunk.  depth 4: mid-tile, drain the copies issued during the previous tile, then issue this tile's
+// (chunk c+3).  depth 3: issue chunk c+2's copies over the first three steps and drain them at step 8, six steps later (with
+// two workgroups per CU a step is ~2 x 192 cycles of wall time): the tile-end barrier certifies them for the read-ahead at
+// the end of tile c+1.
 __device__ __forceinline__ void ring_feed(Ring4 &R, int S)
 {
     if (AG_ABL & 4) return;
-    if (S == 5) { if (!(AG_ABL & 16)) pipe_wait(); ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
-    if (S == 6) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
-    if (S == 7) ring_dma_piece(R, 4);
+    if (R.depth == 4) {
+        if (S == 5) { if (!(AG_ABL & 16)) pipe_wait(); ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
+        if (S == 6) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
+        if (S == 7) ring_dma_piece(R, 4);
+    } else {
+        if (S == 0) { ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
+        if (S == 1) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
+        if (S == 2) ring_dma_piece(R, 4);
+        if (S == 8) { if (!(AG_ABL & 16)) pipe_wait(); }
+    }
 }
 // end of a chunk: barrier (certifies the copies drained mid-tile), rotate
 __device__ __forceinline__ void ring_advance(Ring4 &R)
@@ -390,7 +402,7 @@ __device__ __forceinline__ void ring_advance(Ring4 &R)
     RING_STAMP(R, 4);
     if (!(AG_ABL & 2)) __syncthreads();
     RING_STAMP(R, 5);
-    R.buf = (R.buf + 1) & 3;
+    R.buf = R.buf + 1 == R.depth ? 0 : R.buf + 1;
 }
 // k16-step S of a chunk with NS steps whose step 0 sits in ring slot PH: issue the reads of step S + PF (of the NEXT
 // chunk's first steps once S + PF >= NS: standard image offsets, valid for the compact first-layer chunk too), then
@@ -420,18 +432,17 @@ __device__ __forceinline__ void ring_settle(Ring4 &R)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(R.wq[PHN % 4][0]), "+v"(R.wq[PHN % 4][1]), "+v"(R.wq[(PHN + 1) % 4][0]), "+v"(R.wq[(PHN + 1) % 4][1]));
 }
-// chunks 0, 1, 2 resident and certified, chunk 0's first PF steps in registers; ring slot phase 0
+// chunks 0 .. depth-2 resident and certified, chunk 0's first PF steps in registers; ring slot phase 0
 __device__ __forceinline__ void ring_start(Ring4 &R)
 {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < R.depth - 1; ++c) {
         R.fetch = c < R.total ? c : 0;
-        R.buf = (c + 1) & 3;                                     // target (buf + 3) % 4 = buffer c
+        R.buf = c + 1 == R.depth ? 0 : c + 1;                    // target (buf + depth - 1) % depth = buffer c
 #pragma unroll
         for (int p = 0; p < 5; ++p) ring_dma_piece(R, p);
     }
-    R.fetch = R.total > 3 ? 3 : 0; R.buf = 0;
+    R.fetch = R.total > R.depth - 1 ? R.depth - 1 : 0; R.buf = 0;
     pipe_wait();
     __syncthreads();
     const unsigned la = ring_cur(R, lane);
@@ -581,7 +592,7 @@ struct PrecB3 {
         P.buf ^= 1;
     }
 
-    // ---- NB row blocks per wave (edge_encode64_kernel: NB = 2, one wave per SIMD, 512 registers) -------------------
+    // ---- NB row blocks per wave (edge_encode_nb_kernel; NB = 2: one wave per SIMD, ~410 registers) ---------------------
     // Every weight fragment read from LDS feeds NB B-operand blocks (NB x 32 rows), so a chunk image is copied, read
     // and barriered once per NB x 128 rows of the workgroup: half the L2->LDS DMA bytes, ds_reads and barriers per
     // MFMA at NB = 2.  Each block keeps its own accumulation chain in the same (lo*hi, hi*lo, hi*hi by ascending k16)
@@ -599,7 +610,7 @@ struct PrecB3 {
     __device__ __forceinline__ static void layer_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], const Epi (&epi)[NB], Sink &&sink,
                                                     Carry &&carry)
     {
-        static_assert(NB == 2, "slot -> (block, half) mapping below");
+        static_assert(NB == 1 || NB == 2, "slot -> (block, half) mapping below");
         constexpr int KE = K + (BIAS ? 1 : 0);
         constexpr int NU = (KE + 15) / 16;    // k16-steps per tile
         static_assert(NU == 10, "ring_feed / unit slots assume 10 k16-steps per chunk");
@@ -649,8 +660,8 @@ struct PrecB3 {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[b], acc[b], 0, 0, 0);
                 ring_feed(R, u);
-                if constexpr ((u & 1) && u < 8) {      // slot (u >> 1): units (b0,s0) (b1,s0) (b0,s1) (b1,s1)
-                    constexpr int slot = u >> 1, ub = slot & 1, us = slot >> 1;
+                if constexpr ((u & 1) && u < 8 && (NB == 2 || (u >> 1) % 2 == 0)) {   // slot (u >> 1): units (b0,s0) (b1,s0) (b0,s1) (b1,s1); NB = 1: slots 0, 2
+                    constexpr int slot = u >> 1, ub = NB == 2 ? (slot & 1) : 0, us = slot >> 1;
                     if constexpr (ti > 0) unit(ti - 1, ub, us); else carry(ub, us);
 #if AG_E64_PIN == 2      // ask for an even interleave inside the slot region: 12 x (1 MFMA, 4 VALU)
 #pragma unroll
@@ -690,7 +701,6 @@ struct PrecB3 {
     template <int NB, int K, int PH, class Sink, class Carry>
     __device__ __forceinline__ static void layer_first_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], Sink &&sink, Carry &&carry)
     {
-        static_assert(NB == 2, "unit mapping");
         constexpr int NU = (K + 15) / 16, NS = AG_NT * NU;
         static_assert(NU == 2, "compact first layer: 10 k16-step images per chunk");
         const int lane = threadIdx.x & 63;
@@ -716,8 +726,10 @@ struct PrecB3 {
                 for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].hi[u], acc[b], 0, 0, 0);
                 ring_feed(R, st);
                 // two units per k16-step: step u of out-tile ti finishes half s = u of both blocks of out-tile ti - 1
-                if constexpr (ti == 0) { carry(0, u); carry(1, u); }
-                else {
+                if constexpr (ti == 0) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) carry(b, u);
+                } else {
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -1022,6 +1034,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_
 // barriers per MFMA.  With a single wave per SIMD nothing hides a memory round trip or an epilogue, so the per-edge
 // inputs are fetched split-phase one row tile ahead, the weight ring is four deep with fragments read across the tile
 // barrier, and the epilogue runs in explicit half-tile units pinned between k16-steps (see PrecB3::layer_nb).
+// (edge_encode_nb_kernel<HALF, 2>; <HALF, 1> is the same pipeline with one row block per wave.)
 // Measured (C2, profiles/r02_edge64_*.txt): 0.847 ms per launch vs 0.843 for the 32-row kernel solo, and 99.0 k vs
 // 102.4 k graph-steps/s in the two-stream rollout (a 512-register workgroup owns its CU, so the other stream's HBM-bound
 // kernels cannot co-reside).  Why it does not win: the MFMA pipe-time floor is 1.155 M cycles per launch = 0.58-0.61 ms at
@@ -1030,7 +1043,6 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_
 // row-tile prologue (gathers, first layer: 60 MFMAs against 800 epilogue VALU ops) is exposed: 64 % pipe-busy vs 70 %
 // for two waves per SIMD — and a higher busy fraction is paid back as a lower clock (DVFS).
 // ---------------------------------------------------------------------------------------------
-#define AG_E64_ROWS 256   // edges per workgroup row tile (4 waves x 2 blocks x 32)
 
 struct EdgeRaw {           // raw gathered inputs of one edge (receiver r, sender s), model.py:220-253
     float ar[2], as[2], gr, gs;
@@ -1087,39 +1099,44 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
         for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
 }
 
-template <bool HALF>     // HALF: Eterm is the fp16 table of precision mode 2
-__global__ __launch_bounds__(256, 1) void edge_encode64_kernel(AgWeights w, AgFwdArgs a)
+// NB = row blocks per wave: 2 = the 64-edges-per-wave kernel above (one workgroup per CU, 4-deep ring); 1 = the SAME pipeline with
+// 32 edges per wave, <= 256 registers and a 3-deep ring (60 KB), i.e. two workgroups per CU like edge_encode_kernel<PrecB3> but
+// with the lone-wave machinery (fragment read-ahead across the barrier, pinned epilogue units, split-phase inputs): built to
+// see whether a wave that depends less on its SIMD-mate also runs better next to one.  HALF: Eterm is the fp16 table of mode 2.
+template <bool HALF, int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 1 : 2) void edge_encode_nb_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * AG_CHUNK_FLOATS];
+    constexpr int DEPTH = NB == 2 ? 4 : 3, ROWS = 128 * NB;
+    __shared__ __attribute__((aligned(16))) float lds[DEPTH * AG_CHUNK_FLOATS];
     __shared__ int s_next_tile[2];
     typedef PrecB3 Prec;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int E = a.row_ptr[Mn];
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
-    const int ntiles = (E + AG_E64_ROWS - 1) / AG_E64_ROWS;
+    const int ntiles = (E + ROWS - 1) / ROWS;
     if ((int)blockIdx.x >= ntiles) return;
     // Row tiles are claimed from the per-launch counter TWO ahead (cur is being computed, nxt is being fetched, the
     // claim in flight is the one after): the claimed index travels through LDS under the layers' own barriers.
     int cur = blockIdx.x;
     if (tid == 0) s_next_tile[0] = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
     Ring4 P;
-    P.g = w.edge_encode_b3; P.total = 16; P.fetch = 0; P.lds = lds;
+    P.g = w.edge_encode_b3; P.total = 16; P.fetch = 0; P.lds = lds; P.depth = DEPTH;
     ring_start(P);                                   // (barrier: s_next_tile[0] is visible)
     int nxt = s_next_tile[0], par = 1;
 
-    auto edge_of = [&](int tile, int blk) { return tile * AG_E64_ROWS + wave * 64 + blk * 32 + j; };
-    f32x16 in0[2];
+    auto edge_of = [&](int tile, int blk) { return tile * ROWS + wave * (32 * NB) + blk * 32 + j; };
+    f32x16 in0[NB];
     {
-        EdgeRaw g[2];
+        EdgeRaw g[NB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
             const int e = edge_of(cur, blk);
             const bool valid = e < E;
             edge_gather(a, valid ? a.edge_recv[e] : 0, valid ? a.edge_send[e] : 0, g[blk]);
         }
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) edge_features(a, g[blk], h, in0[blk]);
+        for (int blk = 0; blk < NB; ++blk) edge_features(a, g[blk], h, in0[blk]);
     }
     // Eterm row of (tile, block): fp16 table in precision mode 2 (320-B rows, accumulator order), fp32 otherwise
     typedef std::conditional_t<HALF, RowStoreHalfEpi, RowStoreEpi> EtermEpi;
@@ -1128,8 +1145,10 @@ __global__ __launch_bounds__(256, 1) void edge_encode64_kernel(AgWeights w, AgFw
         if constexpr (HALF) return EtermEpi{reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h};
         else return EtermEpi{a.eterm + e * AG_FP + 4 * h};
     };
-    f32x16 prev[2];                 // unfinished accumulators of the last out-tile (between tiles, layers and row tiles)
-    EtermEpi pend[2] = {{nullptr}, {nullptr}};    // Eterm rows of the previous row tile's last out-tile
+    f32x16 prev[NB];                // unfinished accumulators of the last out-tile (between tiles, layers and row tiles)
+    EtermEpi pend[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) pend[blk] = EtermEpi{nullptr};    // Eterm rows of the previous row tile's last out-tile
     bool have_pend = false;
     auto nosink = [](int, int, int, const f32x16 &) {};
 #if AG_TRACE
@@ -1149,51 +1168,55 @@ __global__ __launch_bounds__(256, 1) void edge_encode64_kernel(AgWeights w, AgFw
         int claimed = 0;
         if (tid == 0) claimed = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
         // phase 1 of the next row tile's inputs: edge indices (land under the first layer)
-        int nr[2], ns[2];
+        int nr[NB], ns[NB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
             const int e = edge_of(nxt, blk);
             const bool valid = e < E;
             nr[blk] = valid ? a.edge_recv[e] : 0;
             ns[blk] = valid ? a.edge_send[e] : 0;
         }
-        typename Prec::Act x[2], y[2];
+        typename Prec::Act x[NB], y[NB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) Prec::set_tile(x[blk], 0, in0[blk]);
+        for (int blk = 0; blk < NB; ++blk) Prec::set_tile(x[blk], 0, in0[blk]);
         // The empty volatile asm pins a unit's result to its slot: pure VALU code has no ordering against the asm
         // statements (fragment reads, waits, DMA) that mark the k16-steps, and instruction selection otherwise sinks it
         // to its first use, a whole layer later.
         auto pin = [](typename Prec::Act &t, int k) { asm volatile("" : "+v"(t.hi[k]), "+v"(t.lo[k])); };
         auto to_y = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(y[blk], ti, s, v); pin(y[blk], 2 * ti + s); };
         auto to_x = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(x[blk], ti, s, v); pin(x[blk], 2 * ti + s); };
-        const NoEpi noepi[2] = {};
+        const NoEpi noepi[NB] = {};
         // fragment-ring phases: 10 k16-steps (first layer) + 3 x 50 per row tile: 0 -> 2 -> 0 -> 2 -> 0 (mod 4)
-        Prec::template layer_first_nb<2, AG_EDGE_IN + 1, 0>(P, x, prev, to_y, [&](int b, int s) {
+        Prec::template layer_first_nb<NB, AG_EDGE_IN + 1, 0>(P, x, prev, to_y, [&](int b, int s) {
             if (have_pend) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, s);     // previous row tile's Eterm, out-tile 4
         });
         RING_STAMP(P, 11);
         if (tid == 0) s_next_tile[par] = claimed;
-        Prec::template layer_nb<2, AG_F, AG_NT, true, true, 2>(P, y, prev, noepi, to_x, [&](int b, int s) {
+        Prec::template layer_nb<NB, AG_F, AG_NT, true, true, 2>(P, y, prev, noepi, to_x, [&](int b, int s) {
             Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);                        // first layer, out-tile 4
         });
         RING_STAMP(P, 13);
-        Prec::template layer_nb<2, AG_F, AG_NT, true, true, 0>(P, x, prev, noepi, to_y, [&](int b, int s) {
+        Prec::template layer_nb<NB, AG_F, AG_NT, true, true, 0>(P, x, prev, noepi, to_y, [&](int b, int s) {
             Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_x, b, s);
         });     // relation_encode
         RING_STAMP(P, 14);
         // phase 2: gather the next row tile's node rows (land under the last layer)
-        EdgeRaw g[2];
+        EdgeRaw g[NB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) edge_gather(a, nr[blk], ns[blk], g[blk]);
+        for (int blk = 0; blk < NB; ++blk) edge_gather(a, nr[blk], ns[blk], g[blk]);
         RING_STAMP(P, 15);
-        const EtermEpi epi[2] = {eterm_row(cur, 0), eterm_row(cur, 1)};
-        Prec::template layer_nb<2, AG_F, AG_NT, false, true, 2>(P, y, prev, epi, nosink, [&](int b, int s) {
+        EtermEpi epi[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) epi[blk] = eterm_row(cur, blk);
+        Prec::template layer_nb<NB, AG_F, AG_NT, false, true, 2>(P, y, prev, epi, nosink, [&](int b, int s) {
             Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);
         });
-        pend[0] = epi[0]; pend[1] = epi[1]; have_pend = true;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) pend[blk] = epi[blk];
+        have_pend = true;
         RING_STAMP(P, 16);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) edge_features(a, g[blk], h, in0[blk]);
+        for (int blk = 0; blk < NB; ++blk) edge_features(a, g[blk], h, in0[blk]);
         RING_STAMP(P, 17);
         cur = nxt;
         nxt = s_next_tile[par];
@@ -1202,7 +1225,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode64_kernel(AgWeights w, AgFw
     }
     if (have_pend) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, sh);
     }
@@ -1492,10 +1515,16 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 {
     if (a.e_cap <= 0) return;
     if (a.precision == AG_PREC_B3 && a.edge_rows == 64 && a.tile_ctr) {     // one 512-register workgroup per CU
-        const int tiles = (a.e_cap + AG_E64_ROWS - 1) / AG_E64_ROWS, slots = a.max_blocks / AG_MLP_WG_PER_CU;
+        const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
         const dim3 grid64(tiles < slots ? tiles : (slots > 0 ? slots : 1));
-        if (a.eterm_half) hipLaunchKernelGGL(edge_encode64_kernel<true>, grid64, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL(edge_encode64_kernel<false>, grid64, dim3(256), 0, s, w, a);
+        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 2>), grid64, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 2>), grid64, dim3(256), 0, s, w, a);
+        return;
+    }
+    if (a.precision == AG_PREC_B3 && a.edge_rows == 33 && a.tile_ctr) {     // 32 rows per wave on the lone-wave pipeline, two workgroups per CU
+        const dim3 grid32(grid_for(a.e_cap, a.max_blocks));
+        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1>), grid32, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1>), grid32, dim3(256), 0, s, w, a);
         return;
     }
     const dim3 grid(grid_for(a.e_cap, a.max_blocks)), block(AG_MLP_THREADS);

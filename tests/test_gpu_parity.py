@@ -242,6 +242,9 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
     m.set_option("edge_rows", 32)
     _, m32 = m(*args, **kw)
+    m.set_option("edge_rows", 33)          # 32 rows per wave on the lone-wave pipeline (two workgroups per CU)
+    _, m33 = m(*args, **kw)
+    assert torch.equal(m32, m33)
     m.set_option("edge_rows", 64)
     _, m64 = m(*args, **kw)
     assert torch.isfinite(m64).all() and torch.equal(m32, m64)

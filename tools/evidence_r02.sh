@@ -10,7 +10,7 @@ for spec in "r32_shipped ab/libbase.so AG_EDGE_ROWS=32" "e64_option ab/libbase.s
 done
 } > $EV/r02_edge64_pmc.txt 2>&1
 {
-echo "# tools/trace_e64.py (-DAG_TRACE=1 build), edge_encode64_kernel final version: (tag:delta cycles) of wave 0, 6th row tile, blocks 0/1/128/129; each stamp costs ~165 cycles"
+echo "# tools/trace_e64.py (-DAG_TRACE=1 build), edge_encode_nb_kernel final version: (tag:delta cycles) of wave 0, 6th row tile, blocks 0/1/128/129; each stamp costs ~165 cycles"
 AG_EDGE_ROWS=64 AG_LIB_PATH=$REPO/ab/libtrace.so timeout 120 python tools/trace_e64.py 2>/dev/null
 } > $EV/r02_edge64_trace.txt
 python bench.py --steps 5 --warmup 2 > $EV/r02_bench.json 2> $EV/bench.err

@@ -1,4 +1,4 @@
-"""Phase trace of one wave's row tile in edge_encode64_kernel (debug build -DAG_TRACE=1): (tag, s_memtime) pairs.
+"""Phase trace of one wave's row tile in edge_encode_nb_kernel (debug build -DAG_TRACE=1): (tag, s_memtime) pairs.
    AG_LIB_PATH=ab/libtrace.so python tools/trace_e64.py
 Tags: 10 row-tile top | 11 first layer done | 12 claim published | 13/14 RE1/RE2 done | 15 gathers issued | 16 We done |
 17 features done | 18 next tile read;  per weight tile: 1 top | 2 k-loop issued | 3 fragments settled | 4 DMA drained | 5 barrier passed."""
