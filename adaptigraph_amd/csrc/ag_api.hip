@@ -132,7 +132,8 @@ struct ag_model {
     size_t dev_floats = 0;
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
-    int fuse_agg = 0;           // 1: segment reduce inside node_update (env AG_FUSE_AGG / "fuse_aggregate"); measured slower
+    int fuse_agg = 0;           // segment reduce inside node_update (env AG_FUSE_AGG / "fuse_aggregate"): 1 = row-per-lane in the MFMA layout (r01,
+                                // measured slower), 2 = cooperative LDS-staged reduce (precision mode 2 only; other modes keep the launch)
     int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3|fast / ag_set_option("precision", 0|1|2)
     int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
@@ -277,9 +278,9 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
 void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
-    a.fuse_agg = m->fuse_agg;
     a.precision = m->precision;
     a.eterm_half = m->eterm_half;
+    a.fuse_agg = (m->fuse_agg == 2 && !(a.precision == AG_PREC_B3 && a.eterm_half)) ? 0 : m->fuse_agg;   // mode 2 of the option needs the fp16 table
     a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
     a.edge_rows = m->edge_rows;
     a.status = m->status;

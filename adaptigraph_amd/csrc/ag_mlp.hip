@@ -1236,16 +1236,34 @@ __global__ __launch_bounds__(256, NB == 2 ? 1 : 2) void edge_encode_nb_kernel(Ag
 // then the node update (model.py:299-301), then either the next round's node-level relation terms (Hr, Hs)
 // or — after the last round — the decoder + clamp + integrate (model.py:306-309).
 // ---------------------------------------------------------------------------------------------
-template <class Prec, bool LAST>
+// FUSE (precision mode 2 only): the round's segment reduce runs INSIDE this kernel, so the `agg` table never exists in HBM
+// (-328 MB of the 2.3 GB a round moves) and the aggregate launch disappears.  The reduce keeps the standalone kernel's memory
+// pattern — 20 adjacent lanes stream one node's 320-byte Eterm rows, 12 nodes per pass of the workgroup — because that pattern,
+// not the MFMA lane layout, is what coalesces (the r01 fusion gathered row-per-lane in the MFMA layout: 0.52 ms vs 0.30 + 0.20).
+// Its sums cross to the owning wave's B-operand registers through a 32-row LDS stage (row stride 164 floats: conflict-free
+// ds_read_b128), one wave's 32 rows at a time.  The two workgroups of a CU are in different phases, so one's latency-bound
+// gather overlaps the other's MFMA chain; row tiles are dealt XCD-contiguously so a graph's sender rows stay in one L2.
+// Measured (C2, r02): 0.474 ms per round vs 0.292 + 0.196 separate (-3 %), 1.97 GB at 4.2 TB/s instead of 2.3 GB at 4.7: the
+// bytes saved are paid back in bandwidth, and in the two-stream rollout the separate kernels co-run better (99 k vs 103 k
+// graph-steps/s), so this is ag_set_option("fuse_aggregate", 2), not the default.  Keeping 8 edges or three nodes per lane in
+// flight changed nothing (0.473 / 0.475 ms): the round is bandwidth-bound at what this access mix reaches, not latency-bound.
+#define AG_STAGE_LD 164
+template <class Prec, bool LAST, bool FUSE>
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
+    __shared__ __attribute__((aligned(16))) float stage[FUSE ? 32 * AG_STAGE_LD : 4];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     ChunkPipe P{LAST ? pick<Prec>(w.node_last, w.node_last_b3) : pick<Prec>(w.node_mid, w.node_mid_b3), LAST ? 16 : 15, 0, 0, lds};
     pipe_start(P);
     TileQueue q(nullptr, s_next_tile);   // ~4 row tiles per workgroup: nothing to balance, static stride
+    if (FUSE) {   // XCD-contiguous deal: block b sits on XCD b % 8; give XCD x the logical ids [x*nb/8, (x+1)*nb/8) so that in every
+                  // round of the grid stride one XCD works on ~nb/8 CONSECUTIVE row tiles (whole graphs)
+        const int nb = gridDim.x, bid = blockIdx.x, qq = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        q.tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
 #pragma unroll 1
     while (q.tile < ntiles) {
         const int tile = q.tile;
@@ -1255,7 +1273,37 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         const int gc = valid ? g : 0;
 
         typename Prec::Act x, y;
-        {
+        if constexpr (FUSE) {
+            const int slot = tid / 20, c = tid - slot * 20, f0 = ag_half_lane_feature(c);
+#pragma unroll 1
+            for (int grp = 0; grp < AG_MLP_WAVES; ++grp) {
+#pragma unroll 1
+                for (int pass = 0; pass < 3; ++pass) {                   // 3 x 12 node slots >= 32 rows
+                    const int r = pass * 12 + slot;
+                    if (tid < 240 && r < 32) {
+                        const int gn = tile * AG_ROWS_PER_BLOCK + grp * 32 + r;
+                        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+                        if (gn < Mn) ag_reduce_node_half(a, gn, c, acc0, acc1);
+                        *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
+                        *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;
+                    }
+                }
+                __syncthreads();
+                if (wave == grp) {
+#pragma unroll
+                    for (int t = 0; t < AG_NT; ++t) {
+                        f32x16 v;
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const float4 u = *reinterpret_cast<const float4 *>(stage + j * AG_STAGE_LD + 32 * t + 8 * qd + 4 * h);
+                            v[4 * qd] = u.x; v[4 * qd + 1] = u.y; v[4 * qd + 2] = u.z; v[4 * qd + 3] = u.w;
+                        }
+                        Prec::set_tile(x, t, v);
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
             f32x16 agg[AG_NT];
             if (a.fuse_agg) { if (a.eterm_half) aggregate_rows<true>(a, gc, valid, h, agg); else aggregate_rows<false>(a, gc, valid, h, agg); }
             else load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
@@ -1536,11 +1584,14 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
 {
     const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
     if (a.precision == AG_PREC_B3) {
-        if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true>), grid, block, 0, s, w, a);
-        else hipLaunchKernelGGL((node_update_kernel<PrecB3, false>), grid, block, 0, s, w, a);
+        if (a.fuse_agg == 2 && a.eterm_half) {      // cooperative LDS-staged reduce inside the kernel (no aggregate launch, no agg table)
+            if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, true>), grid, block, 0, s, w, a);
+            else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true>), grid, block, 0, s, w, a);
+        } else if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false>), grid, block, 0, s, w, a);
     } else {
-        if (last) hipLaunchKernelGGL((node_update_kernel<PrecF32, true>), grid, block, 0, s, w, a);
-        else hipLaunchKernelGGL((node_update_kernel<PrecF32, false>), grid, block, 0, s, w, a);
+        if (last) hipLaunchKernelGGL((node_update_kernel<PrecF32, true, false>), grid, block, 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_kernel<PrecF32, false, false>), grid, block, 0, s, w, a);
     }
 }
 

@@ -56,8 +56,11 @@ int ag_model_destroy(ag_model *m);
 
 /* Engine knobs (all have sane defaults; used by bench.py for A/B passes):
  *   "rollout_streams"  1..4  ag_rollout runs the batch as this many independent parts on separate streams (2)
- *   "fuse_aggregate"   0/1   segment reduce as its own HBM-streaming kernel (0, default) or inside node_update (1)
+ *   "fuse_aggregate"   0/1/2 segment reduce as its own HBM-streaming kernel (0, default), inside node_update row-per-lane (1, slower),
+ *                            or inside node_update through an LDS stage (2, precision 2 only: no `agg` table; measured equal solo, -4 % co-run)
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
+ *   "edge_rows"        32/33/64  split-bf16 edge encoder variant: 32 = default kernel; 64 = two row blocks per wave, one workgroup per CU;
+ *                            33 = 32 rows per wave on that kernel's pipeline (all bit-identical)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
  *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
  *                            2 = mode 1 + the per-edge Eterm table stored as fp16 (2e-6..1.1e-5) (default 2) */

@@ -254,6 +254,28 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     m.set_option("edge_rows", 32)
 
 
+def test_fused_segment_reduce_equals_the_separate_kernel(weights):
+    """ag_set_option("fuse_aggregate", 2): the round's segment reduce inside node_update (no `agg` table, no aggregate launch) adds
+    every node's messages in the same order as aggregate_half_kernel, so outputs are bit-identical to the default path — on a
+    batch with partial row tiles, isolated nodes and a node-count that is not a multiple of 32; other precision modes ignore it."""
+    m = make_model(weights, prec="fast")
+    g = synth.make_graph_inputs("rope", 333, 3, seed=5, spacing=0.1)
+    g["mask"][1, 40:60] = False                                   # a gap: receivers without edges inside a row tile
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
+    _, ref = m(*args, **kw)
+    m.set_option("fuse_aggregate", 2)
+    _, got = m(*args, **kw)
+    assert torch.isfinite(got).all() and torch.equal(ref, got)
+    for _ in range(10):
+        assert torch.equal(m(*args, **kw)[1], got)
+    m.set_option("precision", 1)                                  # fp32 per-edge table: the option falls back to the separate launch
+    _, p1 = m(*args, **kw)
+    m.set_option("fuse_aggregate", 0)
+    assert torch.equal(m(*args, **kw)[1], p1)
+
+
 def test_forward_translation_invariance(model):
     """Positions enter only through differences (model.py:168-173 skipped, :250): shifting the cloud by a
     power-of-two offset (exact in fp32 at this magnitude) leaves pred_motion unchanged to rounding."""
