@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 template <int KIND> struct ChainShape;
 template <> struct ChainShape<0> { static constexpr int L = 4, KF = AG_EDGE_IN + 1, RELU = 0x7; static constexpr bool NARROW = true; };   // RE0 RE1 RE2 We
 template <> struct ChainShape<1> { static constexpr int L = 3, KF = AG_NODE_IN_MAX, RELU = 0x7; static constexpr bool NARROW = true; };   // PE0 PE1 PE2
-template <> struct ChainShape<2> { static constexpr int L = 3, KF = 0, RELU = 0x3; static constexpr bool NARROW = false; };              // D0 D1 D2
+template <> struct ChainShape<2> { static constexpr int L = 3, RELU = 0x3; static constexpr bool NARROW = false; };                      // D0 D1 D2 (wide input: no KF)
 
 struct AgChainArgs {
     const float *x;          // forward input: [rows][d_in] dense (narrow kinds) or [rows][160] (KIND_DEC)
