@@ -286,11 +286,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the engine has no CPU fallback)"
+    local %= max(1, torch.cuda.device_count())       # (a box with fewer GPUs than ranks — the 2-rank test on one GPU — wraps around)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
+        backend = os.environ.get("AG_DIST_BACKEND", "nccl")             # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_seed0.npz")))
     eng = Engine(args.material, weights, dev, world)

@@ -63,3 +63,23 @@ def test_bench_entrypoint_under_torchrun_single_rank():
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["roofline"]["mfma_issue_util"] > line["roofline"]["frac"]
+
+
+def test_bench_two_ranks_one_gpu_over_gloo():
+    """The N > 1 bench path end to end with the real engine: two ranks launched exactly like the driver launches them, both on
+    the one leased GPU, the collective over gloo instead of RCCL (two RCCL ranks cannot share a device).  Checks the contract of
+    the JSON line for N = 2 (global batch, weak scaling, per-rank timings) — not a scaling number."""
+    import json
+    env = dict(os.environ, AG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "24", "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 48 and line["scaling"] == "weak" and line["value"] > 0
+    rk = line["ranks"]
+    assert rk["ms_per_step"]["max"] >= rk["ms_per_step"]["min"] > 0 and rk["all_gather_ms"]["max"] > 0 and rk["rollout_ms"]["min"] > 0
+    assert "extra" not in line and "cpu_baseline" not in line
