@@ -96,10 +96,16 @@ def main():
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench_mpc.py needs an MI355X: the engine has no CPU path")
+    local %= max(1, torch.cuda.device_count())       # fewer GPUs than ranks (2-rank test on one GPU): wrap around
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("AG_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     _lib.lib()
     per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world)
     tt = torch.tensor([per_it], device=dev, dtype=torch.float64)

@@ -83,3 +83,21 @@ def test_bench_two_ranks_one_gpu_over_gloo():
     rk = line["ranks"]
     assert rk["ms_per_step"]["max"] >= rk["ms_per_step"]["min"] > 0 and rk["all_gather_ms"]["max"] > 0 and rk["rollout_ms"]["min"] > 0
     assert "extra" not in line and "cpu_baseline" not in line
+
+
+def test_mpc_bench_two_ranks_one_gpu_over_gloo():
+    """bench_mpc.py (BASELINE configs[4]) with the samples sharded over two ranks: rank 0's sampled actions are broadcast, each
+    rank rolls out its half, the states are all-gathered and every rank runs the cost + MPPI update on the full set.  The
+    per-iteration time must come out of rank 0 as one JSON line; the planner's result must not depend on the sharding (the
+    2-rank reward vector equals the 1-rank one is covered by the bitwise chunk-equality test of the rollout)."""
+    import json
+    env = dict(os.environ, AG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 90), os.path.join(ROOT, "bench_mpc.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--particles", "200", "--samples", "64", "--push-steps", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["parallelism"] == "samples/2"
