@@ -85,7 +85,8 @@ __device__ __forceinline__ unsigned lds_addr_of(const void *p)
 }
 
 #ifndef AG_E64_PIN
-#define AG_E64_PIN 1     // sched_barrier(0) after every epilogue-unit slot of the two-block layers (0: leave placement to the compiler)
+#define AG_E64_PIN 1     // sched_barrier(0) after every epilogue-unit slot of the two-block layers (0: leave placement to the compiler:
+                         // measured 0.901 vs 0.868 ms; an explicit sched_group_barrier interleave of 12 x (1 MFMA, 4 VALU) per slot: 0.905)
 #endif
 #ifndef AG_TRACE
 #define AG_TRACE 0      // debug builds only (tools/trace_tiles.py): s_memtime stamps of one wave's tile phases
@@ -663,13 +664,6 @@ struct PrecB3 {
                 if constexpr ((u & 1) && u < 8 && (NB == 2 || (u >> 1) % 2 == 0)) {   // slot (u >> 1): units (b0,s0) (b1,s0) (b0,s1) (b1,s1); NB = 1: slots 0, 2
                     constexpr int slot = u >> 1, ub = NB == 2 ? (slot & 1) : 0, us = slot >> 1;
                     if constexpr (ti > 0) unit(ti - 1, ub, us); else carry(ub, us);
-#if AG_E64_PIN == 2      // ask for an even interleave inside the slot region: 12 x (1 MFMA, 4 VALU)
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-                    }
-#endif
 #if AG_E64_PIN
                     __builtin_amdgcn_sched_barrier(0);
 #endif
