@@ -58,3 +58,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_training_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks of the row-n4 entry points run before any HIP call: null tables, widths beyond the compiled 150, chain
+    kinds / input widths that do not exist, ragged element counts — all come back as AG_ERR_ARG (-1) with a message."""
+    L = _lib.lib()
+    assert L.ag_train_pack(None, None, 150, 150, 150, 0, 0, 0, 5, 0, None, None) == -1
+    buf = (ctypes.c_float * 8)()
+    assert L.ag_train_pack(buf, None, 150, 151, 151, 0, 0, 0, 5, 0, buf, None) == -1                 # n_in > 150
+    assert L.ag_train_pack(buf, buf, 150, 40, 40, 0, 0, 1, 1, 0, buf, None) == -1                    # compact image holds <= 32 columns
+    arr = (ctypes.c_void_p * 4)()
+    assert L.ag_train_chain(7, 0, 0, buf, buf, arr, None, arr, None, 10, 17, None) == -1               # unknown kind
+    assert L.ag_train_chain(0, 0, 0, buf, buf, arr, None, arr, None, 10, 16, None) == -1               # edge chain takes 17 inputs
+    assert L.ag_train_chain(0, 0, 0, buf, buf, arr, None, arr, None, 10, 17, None) == -1               # null layer table
+    assert b"table 0" in L.ag_last_error()
+    assert L.ag_add3_relu(buf, buf, buf, buf, 6, None) == -1                                           # n % 4 != 0
+    assert L.ag_relu_mask(None, buf, buf, 8, None) == -1
+    i32 = (ctypes.c_int32 * 4)(160, 0, 0, 0)
+    assert L.ag_train_weight_grads(0, arr, i32, arr, i32, i32, 10, buf, buf, 1 << 20, None) == -1      # n_layers < 1
+    assert L.ag_train_weight_grads_workspace_bytes(48000, 4) > L.ag_train_weight_grads_workspace_bytes(1000, 1) > 0
+    assert L.ag_edge_inputs_forward(buf, 15, 2, 14, None, None, None, 0, None) == -1                   # attr + group > D
+    assert L.ag_model_status(None, None, None) == -1

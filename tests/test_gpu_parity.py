@@ -270,6 +270,11 @@ def test_fused_segment_reduce_equals_the_separate_kernel(weights):
     assert torch.isfinite(got).all() and torch.equal(ref, got)
     for _ in range(10):
         assert torch.equal(m(*args, **kw)[1], got)
+    state, act = synth.make_mpc_inputs("rope", 300, 20, seed=4, len_lo=3, len_hi=4.9, spacing=0.1)     # and through the 2-stream rollout
+    fused = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+    m.set_option("fuse_aggregate", 0)
+    assert torch.equal(fused, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
+    m.set_option("fuse_aggregate", 2)
     m.set_option("precision", 1)                                  # fp32 per-edge table: the option falls back to the separate launch
     _, p1 = m(*args, **kw)
     m.set_option("fuse_aggregate", 0)
