@@ -60,6 +60,14 @@ uint16_t bf16_rne(float x)   // round-to-nearest-even, as v_cvt_pk_bf16_f32 does
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+// split-fp16 weight pair (edge stack of precision mode 2): hi = fp16(v) (RNE), lo = fp16(v - hi), subnormals kept
+void f16_split(float v, uint16_t &hi, uint16_t &lo)
+{
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    memcpy(&hi, &h, 2);
+    memcpy(&lo, &l, 2);
+}
 float bf16_to_f32(uint16_t b)
 {
     const uint32_t u = (uint32_t)b << 16;
@@ -70,7 +78,8 @@ float bf16_to_f32(uint16_t b)
 
 // Narrow first layer (fan-in K <= 24, + bias column K): all five out-tiles in ONE chunk image.
 //   F32: [5 tiles][32 rows][32 floats], 16-byte XOR swizzle;  B3: [5 tiles][NU steps][hi|lo][64 lanes][8 bf16]
-void pack_first_layer(std::vector<float> &dst, bool b3, const float *W, int K, int n_out, const float *bias)
+// b3: 0 = fp32 image, 1 = split-bf16 fragment image, 2 = split-fp16 fragment image (same layout)
+void pack_first_layer(std::vector<float> &dst, int b3, const float *W, int K, int n_out, const float *bias)
 {
     const size_t base = dst.size();
     dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
@@ -87,7 +96,8 @@ void pack_first_layer(std::vector<float> &dst, bool b3, const float *W, int K, i
                     c[ti * 1024 + i * 32 + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3)] = v;
                 } else {
                     const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
-                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    if (b3 == 2) f16_split(v, hi, lo);
                     cb[((size_t)((ti * NU + u) * 2 + 0) * 64 + lane) * 8 + e] = hi;
                     cb[((size_t)((ti * NU + u) * 2 + 1) * 64 + lane) * 8 + e] = lo;
                 }
@@ -97,7 +107,7 @@ void pack_first_layer(std::vector<float> &dst, bool b3, const float *W, int K, i
 
 // Append one layer as n_tiles chunk images (AG_CHUNK_FLOATS floats each): input columns [col0, col0+K) of W in
 // image columns [0, K), the bias (if any) in image column K; layout per `b3` as described in ag_common.h.
-void pack_layer(std::vector<float> &dst, bool b3, const float *W, int ld, int col0, int K, int n_out, const float *bias,
+void pack_layer(std::vector<float> &dst, int b3, const float *W, int ld, int col0, int K, int n_out, const float *bias,
                 int n_tiles)
 {
     for (int ti = 0; ti < n_tiles; ++ti) {
@@ -115,7 +125,8 @@ void pack_layer(std::vector<float> &dst, bool b3, const float *W, int ld, int co
                     c[i * AG_WSTRIDE + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3)] = v;
                 } else {
                     const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
-                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    if (b3 == 2) f16_split(v, hi, lo);
                     cb[((size_t)(2 * u + 0) * 64 + lane) * 8 + e] = hi;
                     cb[((size_t)(2 * u + 1) * 64 + lane) * 8 + e] = lo;
                 }
@@ -138,6 +149,9 @@ struct ag_model {
     int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
     double eterm_row_l1 = 0.0;  // max_o sum_k |W_rp[o, k]|, k < nf (bound used by the fp16 Eterm guard)
+    int edge_products = 2;      // precision mode 2: edge stack on two fp16 products per k16-step (fp16 activations x split-fp16 weights);
+                                // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
+    bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
@@ -158,7 +172,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
     const int F = m->cfg.nf, dn = m->cfg.attr_dim + m->cfg.phys_dim + m->cfg.action_dim;
     const int de = 2 * m->cfg.attr_dim + 1 + 3 * m->cfg.n_his;
     std::vector<float> s;
-    s.reserve((size_t)2 * 81 * AG_CHUNK_FLOATS);
+    s.reserve((size_t)(2 * 81 + 16) * AG_CHUNK_FLOATS);
     size_t off[2][4];
     for (int b3 = 0; b3 < 2; ++b3) {
         off[b3][0] = s.size();                                             // node_encode stream
@@ -183,6 +197,11 @@ int pack_and_upload(ag_model *m, const float *const *t)
         pack_layer(s, b3, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
         pack_layer(s, b3, t[W_D2], F, 0, F, 3, t[B_D2], 1);
     }
+    const size_t off_h2 = s.size();                                        // edge_encode stream, split-fp16
+    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0]);
+    pack_layer(s, 2, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
+    pack_layer(s, 2, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
+    pack_layer(s, 2, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
@@ -204,9 +223,23 @@ int pack_and_upload(ag_model *m, const float *const *t)
         }
         m->eterm_row_l1 = worst;
     }
+    // two-product fp16 edge stack (precision mode 2): only if every edge-stack weight and bias is representable in fp16
+    {
+        bool ok = true;
+        auto fits = [&](const float *p, size_t n, size_t ld = 0, size_t cols = 0) {
+            for (size_t i = 0; i < n; ++i) {
+                const float v = ld ? p[(i / cols) * ld + i % cols] : p[i];
+                ok = ok && fabsf(v) <= 65504.0f;
+            }
+        };
+        fits(t[W_RE0], (size_t)F * de); fits(t[B_RE0], F); fits(t[W_RE1], (size_t)F * F); fits(t[B_RE1], F);
+        fits(t[W_RE2], (size_t)F * F); fits(t[B_RE2], F); fits(t[W_RP], (size_t)F * F, 3 * F, F); fits(t[B_RP], F);
+        m->h2_ok = ok;
+    }
     auto at = [&](int b3, int k) { return reinterpret_cast<const float4 *>(m->dev + off[b3][k]); };
     m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
     m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
+    m->w.edge_encode_h2 = reinterpret_cast<const float4 *>(m->dev + off_h2);
     return AG_OK;
 }
 
@@ -283,6 +316,7 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
     a.fuse_agg = (m->fuse_agg == 2 && !(a.precision == AG_PREC_B3 && a.eterm_half)) ? 0 : m->fuse_agg;   // mode 2 of the option needs the fp16 table
     a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
     a.edge_rows = m->edge_rows;
+    a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
     a.status = m->status;
     if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
@@ -335,6 +369,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     if (const char *v = getenv("AG_EDGE_ROWS")) m->edge_rows = atoi(v);
+    if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     {
         int dev = 0;
@@ -564,7 +599,8 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
-    else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
+    else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
+    else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }

@@ -46,6 +46,8 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
     // the same streams as split-bf16 fragment images (precision AG_PREC_B3)
     const float4 *node_encode_b3, *edge_encode_b3, *node_mid_b3, *node_last_b3;
+    // the edge stream as split-fp16 fragment images (same layout as the bf16 ones; precision mode 2, two-product edge stack)
+    const float4 *edge_encode_h2;
 };
 
 struct AgFwdArgs {
@@ -72,6 +74,7 @@ struct AgFwdArgs {
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
     int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
     int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced (ag_model_status)
+    int edge_products; // precision mode 2 only: 2 = fp16 activations x split-fp16 weights in the edge stack (default), 3 = split-bf16 like mode 1
     int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
                        // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };

@@ -27,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef AG_ABL
 #define AG_ABL 0   // timing-only ablation bits for A/B builds (tools/ab_build.sh); 0 in the shipped library
@@ -87,6 +88,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const void *p)
 #ifndef AG_E64_PIN
 #define AG_E64_PIN 1     // sched_barrier(0) after every epilogue-unit slot of the two-block layers (0: leave placement to the compiler:
                          // measured 0.901 vs 0.868 ms; an explicit sched_group_barrier interleave of 12 x (1 MFMA, 4 VALU) per slot: 0.905)
+#endif
+#ifndef AG_H2_WG_PER_CU
+#define AG_H2_WG_PER_CU 3    // edge_encode_kernel<PrecH2>: <= 168 registers, 40 KB LDS per workgroup
 #endif
 #ifndef AG_TRACE
 #define AG_TRACE 0      // debug builds only (tools/trace_tiles.py): s_memtime stamps of one wave's tile phases
@@ -182,6 +186,15 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
 };
 struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
     _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
+    int *status = nullptr;  // model status word: bit 0 is raised when a value does not fit fp16 (|v| > 65504, inf or NaN — which the
+                            // reduce's relu would otherwise turn into a silent 0): one v_cmp per value, the atomic only on overflow
+    __device__ __forceinline__ void check(const f32x16 &v, int r0, int n) const
+    {
+        bool bad = false;
+#pragma unroll
+        for (int r = r0; r < r0 + n; ++r) bad |= !(fabsf(v[r]) <= 65504.0f);
+        if (bad && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
+    }
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
         typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -190,6 +203,7 @@ struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles]
         for (int r = 0; r < 8; ++r) { a[r] = (_Float16)v[r]; b[r] = (_Float16)v[8 + r]; }
         *reinterpret_cast<h8 *>(row + 32 * ti) = a;
         *reinterpret_cast<h8 *>(row + 32 * ti + 8) = b;
+        check(v, 0, 16);
     }
     __device__ __forceinline__ void half(int ti, int s, const f32x16 &v) const
     {
@@ -198,6 +212,7 @@ struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles]
 #pragma unroll
         for (int r = 0; r < 8; ++r) a[r] = (_Float16)v[8 * s + r];
         *reinterpret_cast<h8 *>(row + 32 * ti + 8 * s) = a;
+        check(v, 8 * s, 8);
     }
 };
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
@@ -372,10 +387,12 @@ __device__ __forceinline__ void ring_dma_piece(Ring4 &R, int piece)
 {
     int f = R.fetch;
     asm volatile("" : "+s"(f));     // keep the (cyclic) chunk address out of LICM's reach, as pipe_dma does
-    const float4 *g = R.g + (size_t)f * AG_CHUNK_F4 + threadIdx.x + 256 * piece;
+    const int idx = (int)(threadIdx.x + blockDim.x * piece);        // float4 index inside the chunk (1 280 per chunk)
+    if ((int)((threadIdx.x & ~63u) + blockDim.x * piece) >= AG_CHUNK_F4) return;      // wave-uniform: 512-thread workgroups need 2.5 pieces
+    const float4 *g = R.g + (size_t)f * AG_CHUNK_F4 + idx;
     const int tb = R.buf == 0 ? R.depth - 1 : R.buf - 1;
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)R.lds;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(base + (tb * AG_CHUNK_FLOATS + (threadIdx.x >> 6) * 256) * 4) + 16 * 256 * piece;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(base + tb * AG_CHUNK_FLOATS * 4 + ((threadIdx.x & ~63u) + blockDim.x * piece) * 16);
     dma16(g, dst);
 }
 // k16-step S (of 10) of a chunk.  depth 4: mid-tile, drain the copies issued during the previous tile, then issue this tile's
@@ -747,6 +764,137 @@ struct PrecB3 {
 };
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// H2 ("fp16x2"): TWO products per k16-step instead of three, for the EDGE stack of precision mode 2 only.
+//   activation x -> ONE fp16 (RNE, 11 significant bits);  weight W = hi + lo, two fp16 (lo is mostly subnormal: the fp16 MFMA
+//   honours subnormal inputs on gfx950 — tools/ubench/mfma_f16_denorm.hip — so W carries >= 19 bits, absolute error <= 2^-25);
+//   acc += lo*x; acc += hi*x on v_mfma_f32_32x32x16_f16, fp32 accumulate.
+// Why this is enough HERE and nowhere else: a rounding error of 2^-12 per activation is random and averages out over the
+// 150-term dot products and over the edges summed into a node; emulated in float64 on the reference forwards it costs
+// 1.6e-6 .. 6.4e-6 (tools/two_product_err.py; the gate is 1e-4), less than the fp16 Eterm table mode 2 already uses.  The same
+// rounding on the NODE-level layers costs 2.2e-4 (node states feed three rounds of 20-neighbour sums), and rounding the
+// weights instead of the activations costs 3x more — so node kernels, and modes 0/1 everywhere, keep their arithmetic.
+// What it buys: the edge encoder is power-limited (pure bf16 MFMA chains on random data sustain 1.78 PF at
+// 1 300 W, fp16 chains 1.63 PF), so the only lever is fewer MFMAs: 320 instead of 480 per 32 edges, one convert instead of a
+// 6-op hi/lo split per value pair, and half the operand registers (three workgroups per CU instead of two).
+// An activation beyond +-65504 converts to inf, reaches Eterm as inf/NaN and raises the model's sticky status bit in the
+// segment reduce, exactly like an Eterm overflow (ag_model_status).
+struct PrecH2 {
+    struct Act { f16x8 v[2 * AG_NT]; };
+    __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
+    {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 H;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x2 x = {v[8 * s + 2 * w], v[8 * s + 2 * w + 1]};
+                H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+            }
+            a.v[2 * ti + s] = __builtin_bit_cast(f16x8, H);
+        }
+    }
+
+    // same tile loop as PrecB3::layer (weight ring, fragment prefetch, deferred epilogue), two MFMAs per k16-step
+    template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
+    __device__ __forceinline__ static void layer(ChunkPipe &P, const Act &in, const Init &init, const Epi &epi, Sink &&sink)
+    {
+        constexpr int KE = K + (BIAS ? 1 : 0);
+        constexpr int NU = (KE + 15) / 16;
+        constexpr int PF = 2;
+        const int lane = threadIdx.x & 63, h = lane >> 5;
+        f32x16 prev;
+        auto finish = [&](int ti, f32x16 &v) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = relu1(v[r]);
+            }
+            epi(ti, v);
+            sink(ti, v);
+        };
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+            pipe_dma(P, P.buf ^ 1);
+            f32x16 acc = init(ti);
+            bf16x8 wq[PF + 1][2];
+            static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                lds_read16<(2 * u) * 1024>(wq[u][0], la);
+                lds_read16<(2 * u + 1) * 1024>(wq[u][1], la);
+            });
+            if (ti > 0) finish(ti - 1, prev);
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if constexpr (u + PF < NU) {
+                    lds_read16<(2 * (u + PF)) * 1024>(wq[(u + PF) % (PF + 1)][0], la);
+                    lds_read16<(2 * (u + PF) + 1) * 1024>(wq[(u + PF) % (PF + 1)][1], la);
+                }
+                constexpr int ahead = (NU - 1 - u) < PF ? (NU - 1 - u) : PF;
+                lds_wait_pair<2 * ahead>(wq[u % (PF + 1)][0], wq[u % (PF + 1)][1]);
+                const f16x8 wh = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][0]), wl = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][1]);
+                f16x8 x = in.v[u];
+                if constexpr (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3)
+                    constexpr int o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
+                    if (h == hb) x[e] = (_Float16)1.0f;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, x, acc, 0, 0, 0);
+            });
+            prev = acc;
+            pipe_wait();
+            __syncthreads();
+            P.buf ^= 1;
+        }
+        finish(NT - 1, prev);
+    }
+
+    template <int K, class Sink>
+    __device__ __forceinline__ static void layer_first(ChunkPipe &P, const Act &in, Sink &&sink)
+    {
+        constexpr int NU = (K + 15) / 16;
+        static_assert(NU <= 2, "compact first layer");
+        const int lane = threadIdx.x & 63;
+        const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+        pipe_dma(P, P.buf ^ 1);
+        bf16x8 wq[2][NU][2];
+        static_for<0, NU>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            lds_read16<(u * 2) * 1024>(wq[0][u][0], la);
+            lds_read16<(u * 2 + 1) * 1024>(wq[0][u][1], la);
+        });
+        static_for<0, AG_NT>([&](auto T) {
+            constexpr int ti = decltype(T)::value;
+            if constexpr (ti + 1 < AG_NT)
+                static_for<0, NU>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    lds_read16<(((ti + 1) * NU + u) * 2) * 1024>(wq[(ti + 1) & 1][u][0], la);
+                    lds_read16<(((ti + 1) * NU + u) * 2 + 1) * 1024>(wq[(ti + 1) & 1][u][1], la);
+                });
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            static_for<0, NU>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                constexpr int later = (NU - 1 - u) + (ti + 1 < AG_NT ? NU : 0);
+                lds_wait_pair<2 * later>(wq[ti & 1][u][0], wq[ti & 1][u][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[ti & 1][u][1]), in.v[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[ti & 1][u][0]), in.v[u], acc, 0, 0, 0);
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            sink(ti, acc);
+        });
+        pipe_wait();
+        __syncthreads();
+        P.buf ^= 1;
+    }
+};
+
+
 // layer -> next Act
 template <class Prec, int K, bool RELU, bool BIAS, class Init, class Epi = NoEpi>
 __device__ __forceinline__ void dense(ChunkPipe &P, const typename Prec::Act &in, typename Prec::Act &out, const Init &init,
@@ -864,6 +1012,7 @@ struct TileQueue {
 template <class Prec> __device__ __forceinline__ const float4 *pick(const float4 *f32, const float4 *b3);
 template <> __device__ __forceinline__ const float4 *pick<PrecF32>(const float4 *f32, const float4 *) { return f32; }
 template <> __device__ __forceinline__ const float4 *pick<PrecB3>(const float4 *, const float4 *b3) { return b3; }
+template <> __device__ __forceinline__ const float4 *pick<PrecH2>(const float4 *, const float4 *b3) { return b3; }   // (the caller passes the fp16 image)
 
 // ---------------------------------------------------------------------------------------------
 // Node encoder + pstep-invariant node terms.
@@ -931,8 +1080,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
 //   Eterm      = W_rp[:, :F] . enc_e + b_rp      (first column block of relation_propagator, model.py:289)
 // The one-hot gathers Rr.bmm / Rs.bmm become indexed reads of the (L2-resident) raw node inputs.
 // ---------------------------------------------------------------------------------------------
+template <class Prec> constexpr int kEdgeWgPerCu = AG_MLP_WG_PER_CU;
+template <> constexpr int kEdgeWgPerCu<PrecH2> = AG_H2_WG_PER_CU;
 template <class Prec>
-__global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
+__global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -941,7 +1092,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
-    ChunkPipe P{pick<Prec>(w.edge_encode, w.edge_encode_b3), 16, 0, 0, lds};
+    const bool h2 = std::is_same_v<Prec, PrecH2>;
+    ChunkPipe P{pick<Prec>(w.edge_encode, h2 ? w.edge_encode_h2 : w.edge_encode_b3), 16, 0, 0, lds};
     pipe_start(P);
     TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
 #if AG_TRACE
@@ -1012,7 +1164,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void edge_encode_
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
         if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
-            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h});
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h, a.status});
         else
             dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)e * AG_FP + 4 * h});
         q.next();
@@ -1097,10 +1249,12 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 // 32 edges per wave, <= 256 registers and a 3-deep ring (60 KB), i.e. two workgroups per CU like edge_encode_kernel<PrecB3> but
 // with the lone-wave machinery (fragment read-ahead across the barrier, pinned epilogue units, split-phase inputs): built to
 // see whether a wave that depends less on its SIMD-mate also runs better next to one.  HALF: Eterm is the fp16 table of mode 2.
-template <bool HALF, int NB>
-__global__ __launch_bounds__(256, NB == 2 ? 1 : 2) void edge_encode_nb_kernel(AgWeights w, AgFwdArgs a)
+// WAVES = 8 (with NB = 1): one 512-thread workgroup per CU whose eight waves share ONE weight ring — the L2->LDS stream of the
+// 64-row kernel (1 280 B per edge) with two waves per SIMD; all eight meet at every tile barrier (lock-step).
+template <bool HALF, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (NB == 2 || WAVES == 8) ? 1 : 2) void edge_encode_nb_kernel(AgWeights w, AgFwdArgs a)
 {
-    constexpr int DEPTH = NB == 2 ? 4 : 3, ROWS = 128 * NB;
+    constexpr int DEPTH = (NB == 2 || WAVES == 8) ? 4 : 3, ROWS = 32 * NB * WAVES;
     __shared__ __attribute__((aligned(16))) float lds[DEPTH * AG_CHUNK_FLOATS];
     __shared__ int s_next_tile[2];
     typedef PrecB3 Prec;
@@ -1136,7 +1290,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 1 : 2) void edge_encode_nb_kernel(Ag
     typedef std::conditional_t<HALF, RowStoreHalfEpi, RowStoreEpi> EtermEpi;
     auto eterm_row = [&](int tile, int blk) {
         const size_t e = (size_t)edge_of(tile, blk);
-        if constexpr (HALF) return EtermEpi{reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h};
+        if constexpr (HALF) return EtermEpi{reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h, a.status};
         else return EtermEpi{a.eterm + e * AG_FP + 4 * h};
     };
     f32x16 prev[NB];                // unfinished accumulators of the last out-tile (between tiles, layers and row tiles)
@@ -1559,17 +1713,30 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     if (a.precision == AG_PREC_B3 && a.edge_rows == 64 && a.tile_ctr) {     // one 512-register workgroup per CU
         const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
         const dim3 grid64(tiles < slots ? tiles : (slots > 0 ? slots : 1));
-        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 2>), grid64, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 2>), grid64, dim3(256), 0, s, w, a);
+        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 2, 4>), grid64, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 2, 4>), grid64, dim3(256), 0, s, w, a);
         return;
     }
     if (a.precision == AG_PREC_B3 && a.edge_rows == 33 && a.tile_ctr) {     // 32 rows per wave on the lone-wave pipeline, two workgroups per CU
         const dim3 grid32(grid_for(a.e_cap, a.max_blocks));
-        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1>), grid32, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1>), grid32, dim3(256), 0, s, w, a);
+        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1, 4>), grid32, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1, 4>), grid32, dim3(256), 0, s, w, a);
         return;
     }
-    const dim3 grid(grid_for(a.e_cap, a.max_blocks)), block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3 && a.edge_rows == 34 && a.tile_ctr) {     // eight 32-row waves sharing one ring, one workgroup per CU
+        const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
+        const dim3 grid8(tiles < slots ? tiles : (slots > 0 ? slots : 1));
+        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1, 8>), grid8, dim3(512), 0, s, w, a);
+        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1, 8>), grid8, dim3(512), 0, s, w, a);
+        return;
+    }
+    const dim3 block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
+        const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H2_WG_PER_CU));
+        hipLaunchKernelGGL(edge_encode_kernel<PrecH2>, grid, block, 0, s, w, a);
+        return;
+    }
+    const dim3 grid(grid_for(a.e_cap, a.max_blocks));
     if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(edge_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
     else hipLaunchKernelGGL(edge_encode_kernel<PrecF32>, grid, block, 0, s, w, a);
 }

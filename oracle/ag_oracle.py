@@ -201,7 +201,7 @@ def dynamics(weights, task, state, action, radius=None, phys_value=0.5, pstep=3,
     return seq, decoded
 
 
-def dynamics_masked(weights, task, state_init, state_mask, action, radius=None, phys_value=0.5, pstep=3):
+def dynamics_masked(weights, task, state_init, state_mask, action, radius=None, phys_value=0.5, pstep=3, trace=None):
     """forward_dynamics.py:208-399.  state_init (bsz,n,3), state_mask (bsz,n) bool, action (bsz,4)."""
     state_init, action = _f32(state_init), _f32(action)
     state_mask = np.asarray(state_mask, bool)
@@ -234,7 +234,7 @@ def dynamics_masked(weights, task, state_init, state_mask, action, radius=None, 
     tool_mask[:, n_obj:] = True
     phys = np.full((bsz, 1), phys_value, np.float32)
     seq = _rollout_core(weights, task, states, delta, attrs, p_instance, phys, mask, tool_mask, radius, repeat, n_obj,
-                        height, pstep)
+                        height, pstep, trace)
     return seq, decoded
 
 

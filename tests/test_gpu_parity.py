@@ -19,7 +19,8 @@ from oracle import ag_oracle as ago
 pytestmark = pytest.mark.gpu
 TOL_FWD = 1e-4        # north_star gate (single forward, identical graphs)
 TOL_TIGHT = 2e-5      # 5x inside the gate: exact-fp32 mode measures ~1e-7..1e-6, split-bf16 mode ~1e-6..6e-6
-TOL_BY_PREC = {"f32": 2e-5, "bf16x3": 2e-5, "fast": 4e-5}   # "fast" adds fp16 Eterm storage: measured 2e-6..1.1e-5
+TOL_BY_PREC = {"f32": 2e-5, "bf16x3": 2e-5, "fast": 6e-5}   # gate 1e-4; "fast" (fp16 Eterm table + two-product fp16 edge stack) measures 4e-6..1e-5 on the
+                                                             # reference-scale forwards and 5.0e-5 of max|motion| on the scaled-decoder clamp case
 DEV = "cuda:0"
 
 
@@ -240,11 +241,15 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     assert int(csr.row_ptr[-1].item()) % 256 not in (0, 128)
     args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
     kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
+    m.set_option("edge_products", 3)       # (mode 2's default edge stack is the two-product fp16 one; these kernels are split-bf16)
     m.set_option("edge_rows", 32)
     _, m32 = m(*args, **kw)
     m.set_option("edge_rows", 33)          # 32 rows per wave on the lone-wave pipeline (two workgroups per CU)
     _, m33 = m(*args, **kw)
     assert torch.equal(m32, m33)
+    m.set_option("edge_rows", 34)          # eight 32-row waves sharing one weight ring (one 512-thread workgroup per CU)
+    _, m34 = m(*args, **kw)
+    assert torch.equal(m32, m34)
     m.set_option("edge_rows", 64)
     _, m64 = m(*args, **kw)
     assert torch.isfinite(m64).all() and torch.equal(m32, m64)
@@ -252,6 +257,7 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
         _, again = m(*args, **kw)
         assert torch.equal(m64, again)
     m.set_option("edge_rows", 32)
+    m.set_option("edge_products", 2)
 
 
 def test_fused_segment_reduce_equals_the_separate_kernel(weights):
@@ -336,23 +342,31 @@ def _ppm(material):
     return ppm
 
 
-def explain_divergence(model, weights, material, state, action, b):
-    """Sample b of dynamics(state, action) left the 1e-4 gate.  Walk the REFERENCE trajectory (oracle trace) and at every
-    step run the engine for ONE step from the reference state (identical graph): its prediction must stay inside the gate,
-    and the first step at which the engine's rebuilt edge list differs from the reference's must differ only by candidates
-    whose distance gap (to the competing candidate at the top-k cut, or to the radius) is < 10x that step's measured
-    position deviation.  Returns (step, deviation, gap); raises AssertionError if the divergence has any other cause."""
+def explain_divergence(model, weights, material, state, action, b, state_mask=None):
+    """Sample b of dynamics(state, action) — or, with `state_mask`, of dynamics_masked(state, state_mask, action) — left the
+    1e-4 gate.  Walk the REFERENCE trajectory (oracle trace) and at every step run the engine for ONE step from the reference
+    state (identical graph): its prediction must stay inside the gate, and the first step at which the engine's rebuilt edge
+    list differs from the reference's must differ only by candidates whose distance gap (to the competing candidate at the
+    top-k cut, or to the radius) is < 10x that step's measured position deviation.  Returns (step, deviation, gap); raises
+    AssertionError if the divergence has any other cause."""
     task = configs.task_config(material)
     mm = synth.MATERIALS[material]
     trace = []
-    ago.dynamics(weights, task, state, action[b:b + 1], trace=trace)
+    if state_mask is None:
+        ago.dynamics(weights, task, state, action[b:b + 1], trace=trace)
+        height_mode, obj_mask = _lib.AG_HEIGHT_MIN, None
+    else:
+        ago.dynamics_masked(weights, task, state[b:b + 1], state_mask[b:b + 1], action[b:b + 1], trace=trace)
+        height_mode, obj_mask = _lib.AG_HEIGHT_MASKED_MEAN, t(np.asarray(state_mask[b:b + 1], bool))
+    raise_by = 0.01 * task["sim_real_ratio"] if task["gripper_enable"] else 0.0
     assert len(trace) >= 2, "a one-step rollout cannot diverge through an edge flip"
     one = torch.ones(1, dtype=torch.int32, device=DEV)
     for ai in range(len(trace) - 1):
         tr, nx = trace[ai], trace[ai + 1]
         thr = aggraph.threshold_sq(tr["radius"], 1, torch.device(DEV), _lib.AG_VARIANT_BATCH)
         _, fin = rollout(model, t(tr["states"]), t(tr["delta"]), t(tr["attrs"]), t(tr["p_instance"]), t(tr["phys"]), t(tr["mask"]),
-                         t(tr["tool_mask"]), thr, one, 1, mm["topk"], mm["connect_tools_all"], mm["n_tools"], return_state=True)
+                         t(tr["tool_mask"]), thr, one, 1, mm["topk"], mm["connect_tools_all"], mm["n_tools"], height_mode, obj_mask,
+                         raise_by, return_state=True)
         cur_e, cur_r = fin[0, -1].cpu().numpy(), nx["states"][0, -1]
         dev = float(np.abs(cur_e - cur_r).max())
         assert dev <= TOL_FWD, f"step {ai + 1}: one-step deviation {dev} on the identical graph"
@@ -422,7 +436,11 @@ def test_dynamics_masked_golden(name, weights, prec):
     m = make_model(weights, material, prec=prec)
     out = dynamics_masked(t(g["state_init"]), t(g["state_mask"]), t(g["action"]), m, DEV, _ppm(material))
     assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
-    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= TOL_FWD
+    err = np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).reshape(g["state_seqs"].shape[0], -1).max(1)
+    assert prec != "f32" or (err <= TOL_FWD).all(), f"exact-fp32 mode must match every reference rollout: {err}"
+    for b in np.nonzero(err > TOL_FWD)[0]:      # inside the gate, or a PROVEN top-k near-tie (see explain_divergence)
+        step, dev, gap = explain_divergence(m, weights, material, g["state_init"], g["action"], int(b), state_mask=g["state_mask"])
+        print(f"{name}[{b}] ({prec}): top-k near-tie at step {step}: candidates {gap:.2e} apart, forward deviation {dev:.2e}")
 
 
 def test_dynamics_vs_oracle_rope300(weights, prec):

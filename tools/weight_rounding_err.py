@@ -24,6 +24,24 @@ def csr(n_rel, recv, send, N):
     return CSREdges(t(row_ptr), t(pad(r)), t(pad(s)), B, N, len(r))
 
 
+EDGE_ONLY = len(sys.argv) > 1 and sys.argv[1] == "edge"       # round only the edge-encoder stack (relation_encoder + W_rp[:, :150])
+
+
+def cast_weights(cast):
+    out = {}
+    for k, v in w.items():
+        v = torch.from_numpy(v)
+        if not EDGE_ONLY or k.endswith("bias"):
+            out[k] = cast(v) if not EDGE_ONLY else v
+        elif k.startswith("relation_encoder"):
+            out[k] = cast(v)
+        elif k == "relation_propagator.linear.weight":
+            out[k] = torch.cat([cast(v[:, :150]), v[:, 150:]], 1)
+        else:
+            out[k] = v
+    return out
+
+
 for label, cast in (("exact", lambda x: x), ("fp16 weights", lambda x: x.half().float()), ("bf16 weights", lambda x: x.bfloat16().float())):
     for name in golden_files("fwd_"):
         g = load_golden(name)
@@ -31,7 +49,7 @@ for label, cast in (("exact", lambda x: x), ("fp16 weights", lambda x: x.half().
             continue
         mat = str(g["material"])
         m = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), DEV)
-        m.load_state_dict({k: cast(torch.from_numpy(v)) for k, v in w.items()}); m = m.to(DEV).eval(); m.set_option("precision", 0)
+        m.load_state_dict(cast_weights(cast)); m = m.to(DEV).eval(); m.set_option("precision", 0)
         pos, mot = m(t(g["state"]), t(g["attrs"]), csr(g["n_rel"], g["recv"], g["send"], g["attrs"].shape[1]), None, t(g["p_instance"]),
                      action=t(g["action"]), **{mat + "_physics_param": t(g["phys"])})
         print(f"{label:13s} {name:18s} max-abs {np.abs(mot.cpu().numpy() - g['pred_motion']).max():.3e}")
