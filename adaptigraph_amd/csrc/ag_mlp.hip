@@ -812,13 +812,13 @@ struct PrecH2 {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = relu1(v[r]);
             }
-            epi(ti, v);
+            if (!(AG_ABL & 8) || v[0] == 1234.5678f) epi(ti, v);   // (ablation keeps the value live: no DCE)
             sink(ti, v);
         };
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
-            pipe_dma(P, P.buf ^ 1);
+            if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
             static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
@@ -845,8 +845,8 @@ struct PrecH2 {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, x, acc, 0, 0, 0);
             });
             prev = acc;
-            pipe_wait();
-            __syncthreads();
+            if (!(AG_ABL & 16)) pipe_wait();
+            if (!(AG_ABL & 2)) __syncthreads();
             P.buf ^= 1;
         }
         finish(NT - 1, prev);
