@@ -152,6 +152,7 @@ struct ag_model {
     int edge_products = 2;      // precision mode 2: edge stack on two fp16 products per k16-step (fp16 activations x split-fp16 weights);
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
+    int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
@@ -266,6 +267,7 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
     a.hs_out = c.take<float>(L.rows_pad * AG_FP);
     a.agg = c.take<float>(L.rows_pad * AG_FP);
     a.eterm = c.take<float>(L.e_pad * AG_FP);
+    a.edge_node_tab = c.take<float>(L.rows_pad * 16);
     a.tile_ctr = c.take<int>(AG_TILE_CTRS);
 }
 
@@ -317,6 +319,7 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
     a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
     a.edge_rows = m->edge_rows;
     a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
+    a.edge_ws = m->edge_ws;
     a.status = m->status;
     if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
@@ -369,6 +372,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     if (const char *v = getenv("AG_EDGE_ROWS")) m->edge_rows = atoi(v);
+    if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     {
@@ -600,6 +604,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
+    else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;

@@ -72,9 +72,11 @@ struct AgFwdArgs {
     int eterm_half;    // 1: the Eterm table is fp16 in accumulator order (precision mode 2)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
+    float *edge_node_tab;  // (rows_pad, 16): per-node inputs of the edge features [attr0, attr1, group0, 0, v0(3), v1(3), v2(3), x_cur(3)] (weight-stationary edge encoder)
     int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
     int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced (ag_model_status)
     int edge_products; // precision mode 2 only: 2 = fp16 activations x split-fp16 weights in the edge stack (default), 3 = split-bf16 like mode 1
+    int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
     int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
                        // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };

@@ -1245,6 +1245,447 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
         for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
 }
 
+// =====================================================================================================================
+// Weight-STATIONARY edge encoder (precision mode 2, two-product fp16 arithmetic of PrecH2; the default there, ag_set_option("edge_stationary", 0) selects the streaming kernel).
+//
+// The streaming kernels above re-read the whole 320 KB weight image from L2 through LDS for every 128 edges: 2 560 B of
+// L2->LDS traffic and 2 560 B of LDS fragment reads per edge, against 388 B of HBM traffic; in the power-limited regime
+// this kernel runs in that data movement is what is left to save (timing ablation of the streaming
+// kernel: 0.685 ms, 0.576 without the copies).  Here the dataflow is turned around:
+//  * ONE 256-thread workgroup per CU, one wave per SIMD, 512 registers per lane.  The four layers are cut into 15 "units"
+//    of one 32-feature out-tile (20 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
+//    80 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
+//    the whole launch — 1.2 MB of the CU's 2 MB register file hold the entire edge stack:
+//        wave 0: first layer (its 20 KB of fragments in LDS), RE1 tiles 0-2      wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
+//        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: We tiles 1-4
+//    Three units of a wave sit in the accumulation half of the register file (the MFMA reads its A operand from there
+//    directly), the fourth and all accumulators in the architectural half (the epilogue's VALU instructions read them directly).
+//  * 32-edge blocks flow through the waves as a software pipeline; a layer's 160 x 32 fp16 activation block (10 KB, already in
+//    the B-operand image of the next layer: lane (j, h) writes exactly the 16 bytes lane (j, h) of the consumer reads) is
+//    handed over through LDS: 10 KB written + 10-20 KB read per block and wave instead of 320 KB of weight fragments.
+//  * One barrier per ROUND (80 MFMAs per wave), every buffer a ring of three blocks.  Round r: wave 1 loads the edge indices
+//    of its block i = r, the node rows of i-1 and writes the input features of i-2; the first layer works on i-3, RE1 on
+//    i-4, RE2 on i-6, We on i-8.
+//  * A lone wave hides an instruction only in the shadow of ONE MFMA (~7 issue slots per 32-cycle pass; s_memtime: a
+//    28-instruction epilogue queued behind four back-to-back MFMAs cost its full 110 cycles).  So the MFMAs are issued from
+//    inline asm as (lo, hi) pairs of one accumulator, and after EACH pair runs one "micro-chore" of the previous phase's
+//    epilogue: two accumulator values -> ReLU -> one packed fp16 convert (every fourth: the 16-byte store), or one piece
+//    of the input gather, pinned by sched_barrier.  The accumulators a chore reads were last written four or more MFMAs
+//    earlier (asm MFMAs get no hazard nops from the compiler).
+//  * Each accumulator still sees lo*x then hi*x by ascending k16-step, so results equal edge_encode_kernel<PrecH2> bit for bit.
+// =====================================================================================================================
+#define AG_WS_IMG 10240          // bytes of one activation image: [10 k16-steps][64 lanes][8 fp16]
+#define AG_WS_IN0 2048           // first-layer input image: 2 k16-steps
+#define AG_WS_SLOTS 3
+#ifndef AG_WS_ABL
+#define AG_WS_ABL 0           // timing-only ablations (debug builds): 1 = no epilogue / gather chores, 2 = chores without their LDS / global stores
+#endif
+#define AG_WS_LAG_F 3
+#define AG_WS_LAG_1 4
+#define AG_WS_LAG_2 6
+#define AG_WS_LAG_3 8
+
+typedef f16x8 WsUnit[10][2];     // A-operand fragments of one (layer, out-tile) unit: [k16-step][hi | lo]
+typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+
+// ACC: keep the unit in the accumulation-register half of the file; a wave holds three units (240 registers) there.
+template <bool ACC>
+__device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 10; ++u)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) W[u][hl] = *reinterpret_cast<const f16x8 *>(chunk + (2 * u + hl) * 64 + lane);
+#pragma unroll
+    for (int u = 0; u < 10; ++u)          // (after ALL the loads: the asm is a use, and a use waits for its load)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            // an opaque value: it must live in a register and cannot be re-loaded inside the persistent loop
+            if (ACC) asm volatile("" : "+a"(W[u][hl]));
+            else asm volatile("" : "+v"(W[u][hl]));
+        }
+}
+template <int N>
+__device__ __forceinline__ void ws_wait(bf16x8 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void ws_wait2(bf16x8 &a, bf16x8 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
+// acc (+)= W . x from inline asm: accumulator and B operand in architectural registers, A operand where the unit lives
+template <bool ACC, bool FIRST>
+__device__ __forceinline__ void ws_mfma(f32x16 &acc, const f16x8 &w, const bf16x8 &x)
+{
+    if constexpr (FIRST) {
+        if constexpr (ACC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(x));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x));
+    } else {
+        if constexpr (ACC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    }
+}
+
+// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input image at LDS address la0, accumulators
+// [NA0, NA0 + NA1) the following units on the image at la1; units with index < NACC live in accumulation registers.
+// An accumulator's lo and hi MFMA of a k16-step are issued BACK TO BACK with nothing in between (the dependent MFMA then
+// uses the pipe's accumulate path; one MFMA of another chain in between leaves it waiting for the write-back: s_memtime,
+// 40 cycles per MFMA instead of 32), and the next pair on the same accumulator follows >= 2 MFMAs later.
+// slot(IC<p>) runs after pair p = u * NA + k (p = 0 .. 10 NA - 1).
+// The three-deep fragment ring q0 / q1 is the caller's: with NEXT_NIN > 0 the phase also issues the first two k16-steps of
+// the NEXT phase (NEXT_NIN input images at na0 / na1) during its own steps 8 and 9, and that phase is instantiated with
+// PRE = true and the ring offset RO = 1 (its step s sits in ring slot (s + RO) % 3): no exposed LDS round trip between phases.
+template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, class Slot>
+__device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0 + NA1], bf16x8 (&q0)[3], bf16x8 (&q1)[3], unsigned la0, unsigned la1,
+                                         unsigned na0, unsigned na1, Slot &&slot)
+{
+    constexpr int NIN = NA1 ? 2 : 1, NA = NA0 + NA1;
+    static_assert(NA >= 2, "a lone accumulator chain would have every chore between its dependent MFMAs");
+    auto issue = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s < 10) {
+            lds_read16<s * 1024>(q0[(s + RO) % 3], la0);
+            if constexpr (NA1 > 0) lds_read16<s * 1024>(q1[(s + RO) % 3], la1);
+        } else if constexpr (NEXT_NIN > 0) {
+            lds_read16<(s - 10) * 1024>(q0[(s + RO) % 3], na0);
+            if constexpr (NEXT_NIN > 1) lds_read16<(s - 10) * 1024>(q1[(s + RO) % 3], na1);
+        }
+    };
+    if constexpr (!PRE) {
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+    }
+    static_for<0, 10>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        issue(std::integral_constant<int, u + 2>{});
+        constexpr int n1 = (u + 1 < 10) ? NIN : NEXT_NIN, n2 = (u + 2 < 10) ? NIN : NEXT_NIN;      // reads issued after step u's
+        if constexpr (NA1 > 0) ws_wait2<n1 + n2>(q0[(u + RO) % 3], q1[(u + RO) % 3]); else ws_wait<n1 + n2>(q0[(u + RO) % 3]);
+        static_for<0, NA>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            ws_mfma<(U0 + k < NACC), (u == 0)>(acc[k], W[U0 + k][u][1], k < NA0 ? q0[(u + RO) % 3] : q1[(u + RO) % 3]);      // lo
+            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? q0[(u + RO) % 3] : q1[(u + RO) % 3]);         // hi
+            if constexpr (!(AG_WS_ABL & 1)) slot(std::integral_constant<int, u * NA + k>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+}
+
+// Epilogue micro-chores.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values).
+// Hidden layers: ReLU, packed fp16 convert; the fourth dword stores the consumer's 16 bytes (bias column: feature 150 := 1.0).
+template <int T, int M>
+__device__ __forceinline__ void ws_act_micro(const f32x16 &acc, ws_u32x4 &H, unsigned char *img_lane, int h)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    constexpr int S = M >> 2, w = M & 3;
+    const f32x2 x = {relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1])};
+    H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    if constexpr (w == 3) {
+        if constexpr (T == 4 && S == 1) {           // feature 150 = 16*9 + 6: element e = 2 of the h = 1 half
+            if (h == 1) H[1] = (H[1] & 0xffff0000u) | 0x3c00u;
+        }
+        if (!(AG_WS_ABL & 2) || H[0] == 0x12345678u) *reinterpret_cast<ws_u32x4 *>(img_lane + (2 * T + S) * 1024) = H;
+    }
+}
+// We: packed fp16 convert of the raw values; `bad` keeps the largest |fp16| bit pattern per half-word (>= 0x7c00: inf or NaN,
+// i.e. |v| > 65504 or a non-finite accumulator); the fourth dword stores 16 bytes of the Eterm row, the last one of a tile tests `bad`.
+template <int T, int M>
+__device__ __forceinline__ void ws_eterm_micro(const f32x16 &acc, ws_u32x4 &H, unsigned &bad, _Float16 *row)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    constexpr int S = M >> 2, w = M & 3;
+    const f32x2 x = {acc[8 * S + 2 * w], acc[8 * S + 2 * w + 1]};
+    H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    bad = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, bad), __builtin_bit_cast(u16x2, H[w] & 0x7fff7fffu)));
+    if constexpr (w == 3) {
+        if (!(AG_WS_ABL & 2) || H[0] == 0x12345678u) *reinterpret_cast<ws_u32x4 *>(row + 32 * T + 8 * S) = H;
+    }
+}
+// Branch-free on purpose: a store under `if (block is valid)` made the compiler sink the whole tile's converts into the
+// conditional block (one 30-instruction lump instead of eight micro-chores).  Rows of blocks outside the launch go to 32 dump
+// rows behind the table (the fp16 table uses half of its fp32-sized allocation); `bad` is tested once, when the wave is done
+// (every LDS buffer starts zeroed, so rounds of the pipeline's fill and drain convert finite values).
+__device__ __forceinline__ void ws_report(unsigned bad, int *status)
+{
+    if (((bad + 0x04000400u) & 0x80008000u) && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
+}
+
+// End of a round: LDS writes of this wave landed, then the workgroup barrier.  NOT __syncthreads(): its workgroup-scope fence also
+// drains vmcnt, i.e. it would wait at every round for the Eterm stores (and gather loads) issued a few hundred cycles earlier.
+__device__ __forceinline__ void ws_round_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Per-node inputs of the edge features (model.py:155-165, 220-253), 64 bytes per node, so that the weight-stationary kernel's
+// gather is two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].
+// The per-edge features are then plain differences of two rows — the same subtractions in the same order as
+// (pr[i+1] - pr[i]) - (ps[i+1] - ps[i]) in edge_features.
+__global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.B * a.N) return;
+    const int b = g / a.N, i = g - b * a.N;
+    float p[AG_NHIS][3];
+#pragma unroll
+    for (int hh = 0; hh < AG_NHIS; ++hh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[hh][c] = a.state[(((size_t)b * AG_NHIS + hh) * a.N + i) * 3 + c];
+    float o[16];
+    o[0] = a.attrs[(size_t)g * 2]; o[1] = a.attrs[(size_t)g * 2 + 1];
+    o[2] = (a.n_inst > 0 && i < a.n_p) ? a.p_instance[((size_t)b * a.n_p + i) * a.n_inst] : 0.0f;
+    o[3] = 0.0f;
+#pragma unroll
+    for (int hh = 0; hh + 1 < AG_NHIS; ++hh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[4 + hh * 3 + c] = p[hh + 1][c] - p[hh][c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[4 + (AG_NHIS - 1) * 3 + c] = p[AG_NHIS - 1][c];
+    float4 *dst = reinterpret_cast<float4 *>(a.edge_node_tab + (size_t)g * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
+__global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_act[3][AG_WS_SLOTS][AG_WS_IMG];   // inputs of RE1, RE2, We: rings of three blocks
+    __shared__ __attribute__((aligned(16))) unsigned char s_in0[AG_WS_SLOTS][AG_WS_IN0];      // first-layer inputs
+    __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Mn = a.B * a.N;
+    const int E = a.row_ptr[Mn];
+    if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
+    const int nblk = (E + 31) / 32;
+    if ((int)blockIdx.x >= nblk) return;
+    const int n_i = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup: blockIdx + i * gridDim
+    const int rounds = n_i + AG_WS_LAG_3 + 2;
+    const float4 *ws = w.edge_encode_h2;
+    for (int i = tid; i < AG_CHUNK_F4; i += 256) s_wf[i] = ws[i];
+    for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 256) reinterpret_cast<float4 *>(&s_act[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 256) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
+    auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
+    auto img = [&](int layer, int i) { return &s_act[layer][slot_of(i)][lane * 16]; };        // this lane's 16 bytes of k16-step 0
+    auto block_ok = [&](int i) { return i >= 0 && i < n_i; };
+    auto eterm_row = [&](int i) {
+        const size_t e = (block_ok(i) ? (size_t)gblock(i) * 32 : e_pad) + j;
+        return reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h;
+    };
+    WsUnit W[4];
+    ws_u32x4 H = {0u, 0u, 0u, 0u};
+    // accumulators start at zero: the first rounds' chores convert them before any MFMA has written them (register garbage would raise `bad`)
+    auto zero = [](auto &arr) {
+        for (auto &v : arr)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = 0.0f;
+    };
+#if AG_TRACE
+    int tr = 0;
+#define WS_STAMP(TAG) do { if (blockIdx.x == 3 && r >= 100 && r < 108 && tr < 256) { ag_trace_buf[wave * 512 + 2 * tr] = (TAG); ag_trace_buf[wave * 512 + 2 * tr + 1] = __builtin_readcyclecounter(); ++tr; } } while (0)
+#else
+#define WS_STAMP(TAG) do { } while (0)
+#endif
+
+    if (wave == 0) {
+        // ---------------------------------------------------------------- first layer, RE1 tiles 0-2
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + k) * AG_CHUNK_F4, lane);
+        __syncthreads();
+        f32x16 accF[5], accP[3];
+        zero(accF); zero(accP);
+        const unsigned wf = lds_addr_of(s_wf) + lane * 16;
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            WS_STAMP(1);
+            const int i0 = r - AG_WS_LAG_F, i1 = r - AG_WS_LAG_1;
+            unsigned char *outF = img(0, i0), *outPp = img(1, i1 - 1);
+            // first layer of block i0: 5 out-tiles x 2 k16-steps x (lo, hi), A fragments from LDS (five independent chains);
+            // shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores in 20 slots)
+            {
+                const unsigned lin = lds_addr_of(&s_in0[slot_of(i0)][lane * 16]);
+                bf16x8 xq[2], fq[2][5];
+                lds_read16<0>(xq[0], lin);
+                lds_read16<1024>(xq[1], lin);
+                static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + 0) * 2 + 1) * 1024>(fq[0][t], wf); });
+                static_for<0, 4>([&](auto G) {
+                    constexpr int g = decltype(G)::value, u = g >> 1;          // groups: (u0, lo) (u0, hi) (u1, lo) (u1, hi)
+                    if constexpr (g < 3) {
+                        constexpr int nu = (g + 1) >> 1, nhl = 1 - ((g + 1) & 1);
+                        static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + nu) * 2 + nhl) * 1024>(fq[(g + 1) & 1][t], wf); });
+                    }
+                    static_for<0, 5>([&](auto T) {
+                        constexpr int t = decltype(T)::value;
+                        constexpr int later = (4 - t) + (g < 3 ? 5 : 0);
+                        ws_wait2<later>(fq[g & 1][t], xq[u]);
+                        ws_mfma<false, (g == 0)>(accF[t], __builtin_bit_cast(f16x8, fq[g & 1][t]), xq[u]);
+                        constexpr int m = g * 5 + t;                           // 0..19
+                        if constexpr (m < 4) {                                 // two micro-chores in the first four slots
+                            ws_act_micro<0, 2 * m>(accP[0], H, outPp, h);
+                            ws_act_micro<0, 2 * m + 1>(accP[0], H, outPp, h);
+                        } else {
+                            constexpr int c = m + 4;                           // 8..23
+                            ws_act_micro<c / 8, c % 8>(accP[c / 8], H, outPp, h);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+            WS_STAMP(2);
+            const unsigned la = lds_addr_of(img(0, i1));
+            bf16x8 q0[3], q1[3];
+            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, q0, q1, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish the first layer (40 micro-chores in 30 slots)
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 10) {
+                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], H, outF, h);
+                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], H, outF, h);
+                } else {
+                    constexpr int c = p + 10;                           // 20..39
+                    ws_act_micro<c / 8, c % 8>(accF[c / 8], H, outF, h);
+                }
+            });
+            WS_STAMP(3);
+            ws_round_barrier();
+            WS_STAMP(4);
+        }
+    } else if (wave == 1) {
+        // ---------------------------------------------------------------- RE1 tiles 3-4, RE2 tiles 0-1, per-edge input gather
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + 3 + k) * AG_CHUNK_F4, lane);
+        ws_load_unit<true>(W[2], ws + (size_t)(6 + 0) * AG_CHUNK_F4, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(6 + 1) * AG_CHUNK_F4, lane);
+        __syncthreads();
+        f32x16 accP[2], accQ[2];
+        zero(accP); zero(accQ);
+        // The gather of one block's inputs (model.py:220-253) is cut into pieces of a few instructions, one per MFMA-pair slot,
+        // three blocks in flight: edge indices (this round) -> the two 64-byte node rows (next round) -> features (the round after).
+        int er = 0, es = 0;                // indices of block r (loaded in round r, used in round r + 1)
+        float4 R[4], S[4];                 // receiver / sender rows of block r - 1 (loaded in round r, used in round r + 1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float feat[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
+        const float4 *tab = reinterpret_cast<const float4 *>(a.edge_node_tab);
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            WS_STAMP(1);
+            const int i1 = r - AG_WS_LAG_1, i2 = r - AG_WS_LAG_2;
+            const unsigned la1 = lds_addr_of(img(0, i1)), la2 = lds_addr_of(img(1, i2));
+            unsigned char *out1 = img(1, i1), *out2p = img(2, i2 - 1);
+            bf16x8 q0[3], q1[3];
+            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, q0, q1, la1, la1, la2, la2, [&](auto PP) {      // RE1 tiles 3, 4;  shadow: finish RE2 tiles 0, 1 of the previous block
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], H, out2p, h);
+                // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1]
+                if constexpr (p == 14) {
+                    feat[0] = R[0].x; feat[1] = R[0].y; feat[2] = S[0].x; feat[3] = S[0].y; feat[4] = fabsf(R[0].z - S[0].z); feat[AG_EDGE_IN] = 1.0f;
+                    feat[5] = R[1].x - S[1].x; feat[6] = R[1].y - S[1].y; feat[7] = R[1].z - S[1].z; feat[8] = R[1].w - S[1].w;
+                }
+                if constexpr (p == 15) {
+                    feat[9] = R[2].x - S[2].x; feat[10] = R[2].y - S[2].y; feat[11] = R[2].z - S[2].z; feat[12] = R[2].w - S[2].w;
+                    feat[13] = R[3].x - S[3].x; feat[14] = R[3].y - S[3].y; feat[15] = R[3].z - S[3].z; feat[16] = R[3].w - S[3].w;
+                }
+                // lane half h keeps features 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (16..23, rest zero)
+                if constexpr (p == 16 || p == 17) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    constexpr int s16 = p - 16;
+                    ws_u32x4 X = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int q = 2 * s16; q < 2 * s16 + 2 && q < 3; ++q)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            const f32x2 v = {h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]};
+                            X[2 * (q - 2 * s16) + c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+                        }
+                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024 * s16]) = X;
+                }
+            });
+            WS_STAMP(2);
+            static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
+            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, q0, q1, la2, la2, la2, la2, [&](auto PP) {      // RE2 tiles 0, 1;  shadow: finish RE1 tiles 3, 4
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], H, out1, h);
+                // node rows of block r - 1 (indices loaded last round): 2 x 64 bytes, one 16-byte load per piece
+                if constexpr (p >= 6 && p < 14) {
+                    constexpr int q = (p - 6) & 3;
+                    if constexpr ((p - 6) < 4) R[q] = tab[(unsigned)er * 4u + q];
+                    else S[q] = tab[(unsigned)es * 4u + q];
+                }
+                if constexpr (p == 18) {                                // edge indices of block r
+                    const int e = (r < n_i ? gblock(r) : 0) * 32 + j;
+                    const bool valid = r < n_i && e < E;
+                    er = valid ? a.edge_recv[e] : 0;
+                    es = valid ? a.edge_send[e] : 0;
+                }
+            });
+            WS_STAMP(3);
+            ws_round_barrier();
+            WS_STAMP(4);
+        }
+    } else if (wave == 2) {
+        // ---------------------------------------------------------------- RE2 tiles 2-4, We tile 0
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(6 + 2 + k) * AG_CHUNK_F4, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(11 + 0) * AG_CHUNK_F4, lane);
+        __syncthreads();
+        f32x16 accP[2], accQ[2];
+        zero(accP); zero(accQ);
+        unsigned bad = 0;
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            WS_STAMP(1);
+            const int i2 = r - AG_WS_LAG_2, i3 = r - AG_WS_LAG_3;
+            const unsigned la2 = lds_addr_of(img(1, i2)), la3 = lds_addr_of(img(2, i3));
+            unsigned char *out2 = img(2, i2), *out2p = img(2, i2 - 1);
+            _Float16 *rowp = eterm_row(i3 - 1);
+            bf16x8 q0[3], q1[3];
+            ws_phase<0, 2, 0, 3, false, 0, 2>(W, accP, q0, q1, la2, la2, la2, la3, [&](auto PP) {      // RE2 tiles 2, 3;  shadow: finish RE2 tile 4 and We tile 0 of the previous blocks
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], H, out2p, h);
+                if constexpr (p >= 8 && p < 16) ws_eterm_micro<0, p - 8>(accQ[1], H, bad, rowp);
+            });
+            WS_STAMP(2);
+            ws_phase<2, 1, 1, 3, true, 1, 0>(W, accQ, q0, q1, la2, la3, la2, la3, [&](auto PP) {      // RE2 tile 4 + We tile 0
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], H, out2, h);
+            });
+            WS_STAMP(3);
+            ws_round_barrier();
+            WS_STAMP(4);
+        }
+        ws_report(bad, a.status);
+    } else {
+        // ---------------------------------------------------------------- We tiles 1-4
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(11 + 1 + k) * AG_CHUNK_F4, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(11 + 4) * AG_CHUNK_F4, lane);
+        __syncthreads();
+        f32x16 accP[2], accQ[2];
+        zero(accP); zero(accQ);
+        unsigned bad = 0;
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            WS_STAMP(1);
+            const int i3 = r - AG_WS_LAG_3;
+            const unsigned la3 = lds_addr_of(img(2, i3));
+            _Float16 *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
+            bf16x8 q0[3], q1[3];
+            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, q0, q1, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: store We tiles 3, 4 of the previous block
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 16) ws_eterm_micro<3 + p / 8, p % 8>(accQ[p / 8], H, bad, rowp);
+            });
+            WS_STAMP(2);
+            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, q0, q1, la3, la3, la3, la3, [&](auto PP) {      // We tiles 3, 4;  shadow: store We tiles 1, 2
+                constexpr int p = decltype(PP)::value;
+                if constexpr (p < 16) ws_eterm_micro<1 + p / 8, p % 8>(accP[p / 8], H, bad, row);
+            });
+            WS_STAMP(3);
+            ws_round_barrier();
+            WS_STAMP(4);
+        }
+        ws_report(bad, a.status);
+    }
+}
+
 // NB = row blocks per wave: 2 = the 64-edges-per-wave kernel above (one workgroup per CU, 4-deep ring); 1 = the SAME pipeline with
 // 32 edges per wave, <= 256 registers and a 3-deep ring (60 KB), i.e. two workgroups per CU like edge_encode_kernel<PrecB3> but
 // with the lone-wave machinery (fragment read-ahead across the barrier, pinned epilogue units, split-phase inputs): built to
@@ -1732,6 +2173,12 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     }
     const dim3 block(AG_MLP_THREADS);
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
+        if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
+            const int blocks = (a.e_cap + 31) / 32, slots = a.max_blocks / AG_MLP_WG_PER_CU;
+            hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), block, 0, s, w, a);
+            return;
+        }
         const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H2_WG_PER_CU));
         hipLaunchKernelGGL(edge_encode_kernel<PrecH2>, grid, block, 0, s, w, a);
         return;

@@ -260,6 +260,36 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     m.set_option("edge_products", 2)
 
 
+@pytest.mark.parametrize("material,n_obj,batch,kw", [
+    ("rope", 700, 5, dict(spacing=0.1)),          # partial last 32-edge block, more blocks than workgroups
+    ("rope", 40, 1, dict(spacing=0.1)),           # fewer blocks than the pipeline is deep
+    ("granular", 2000, 2, {}),                    # saturated top-20 rows
+    ("cloth", 1024, 3, {}),                       # connect_tools_all rows
+])
+def test_weight_stationary_edge_encoder_is_bitwise_the_streaming_kernel(weights, material, n_obj, batch, kw):
+    """Precision mode 2 runs its edge stack on the weight-stationary kernel by default (weights in registers, 32-edge blocks
+    pipelined through the four waves of one workgroup per CU, inline-asm MFMAs); ag_set_option("edge_stationary", 0) selects
+    the streaming kernel with the same two-product fp16 arithmetic.  Every row keeps its accumulation order, so the outputs
+    must be bit-identical and repeatable — which also pins the hand-managed MFMA hazards and LDS hand-over of the new kernel."""
+    m = make_model(weights, material, prec="fast")
+    g = synth.make_graph_inputs(material, n_obj, batch, seed=17, **kw)
+    mm = synth.MATERIALS[material]
+    csr = aggraph.build_edges(t(g["state"][:, -1]), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"], mm["connect_tools_all"],
+                              "batch", max_tools=g["n_tools"])
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw2 = {"action": t(g["action"]), material + "_physics_param": t(g["phys"])}
+    m.set_option("edge_stationary", 0)
+    _, ref = m(*args, **kw2)
+    m.set_option("edge_stationary", 1)
+    _, out = m(*args, **kw2)
+    assert torch.isfinite(out).all() and torch.equal(ref, out)
+    for _ in range(10):
+        _, again = m(*args, **kw2)
+        assert torch.equal(out, again)
+    assert m.take_status() == 0
+
+
+
 def test_fused_segment_reduce_equals_the_separate_kernel(weights):
     """ag_set_option("fuse_aggregate", 2): the round's segment reduce inside node_update (no `agg` table, no aggregate launch) adds
     every node's messages in the same order as aggregate_half_kernel, so outputs are bit-identical to the default path — on a
