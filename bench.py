@@ -12,10 +12,11 @@ the state/tool update for every graph.  Multi-GPU: the batch shards across ranks
 (weak scaling: per-GPU batch fixed), then ONE RCCL all-gather of the predicted states (north_star).
 
 Prints one JSON line on rank 0 (contract in the task statement) with
-  roofline      edge_encode_kernel (MFMA-bound): achieved = F_min FLOP (140 100 per edge) x edges per
+  roofline      the edge encoder (MFMA-bound): achieved = F_min FLOP (140 100 per edge) x edges per
                 launch / average launch time, measured live with HIP events on the launch stream in a single-stream
-                pass, against the dense bf16 MFMA peak (split-bf16 modes) or the fp32 MFMA peak (f32 mode);
-                `mfma_issue_util` = the same with the 3 bf16 products per fp32 product the split modes issue;
+                pass, against the dense bf16/f16 MFMA peak (split modes) or the fp32 MFMA peak (f32 mode);
+                `mfma_issue_util` = the same with the 2 (mode "fast": f16 x split-f16) or 3 (split-bf16) MFMAs the edge stack
+                issues per fp32 product;
                 `traffic` = HBM bytes per launch from the PMC passes recorded in profiles/pmc_traffic.json, used only
                 if that file was collected from the kernel sources being run (sha256 of adaptigraph_amd/csrc), else null
   roofline_hbm  the segment-reduce kernel (HBM-bound), same accounting against 8 TB/s
@@ -55,7 +56,10 @@ FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # F_min edge work: encoder 17->
 PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
 DTYPE = {"f32": "f32 (exact fp32 MFMA)",
          "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
-         "fast": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate; per-edge table stored f16"}
+         "fast": "node stacks: f32 operands split hi+lo bf16, 3 bf16 MFMAs per product; edge stack: f16 activations x split-f16 (hi+lo) "
+                 "weights, 2 f16 MFMAs per product; f32 accumulate; per-edge table stored f16"}
+EDGE_PRODUCTS = {"f32": 1, "bf16x3": 3, "fast": 2}     # MFMAs issued per fp32 product in the edge stack
+DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16x2+bf16x3"}
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -244,12 +248,15 @@ class Engine:
             peak = PEAK_BF16_MFMA_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
             achieved = FLOP_PER_EDGE * e_per / avg_s / 1e12           # algorithmic (F_min) FLOP only
             traffic, src = pmc_traffic(self.material, batch, precision, "edge_encode")
-            roof = {"bound": "mfma", "kernel": "edge_encode_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            kname = {"f32": "edge_encode_kernel<PrecF32>", "bf16x3": "edge_encode_kernel<PrecB3>",
+                     "fast": "edge_encode_ws_kernel (+ edge_node_tab_kernel)"}[precision]
+            roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
-                    "mfma_issue_util": (3 if b3 else 1) * achieved / peak,
+                    "mfma_issue_util": EDGE_PRODUCTS[precision] * achieved / peak,
                     "algorithmic_bytes": e_per * ((320 if precision == "fast" else 640) + 68),
                     "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": FLOP_PER_EDGE,
-                    "mfma": "v_mfma_f32_32x32x16_bf16, 3 per fp32 product (hi*hi + hi*lo + lo*hi)" if b3 else "v_mfma_f32_32x32x2_f32",
+                    "mfma": {"f32": "v_mfma_f32_32x32x2_f32", "bf16x3": "v_mfma_f32_32x32x16_bf16, 3 per fp32 product (hi*hi + hi*lo + lo*hi)",
+                             "fast": "v_mfma_f32_32x32x16_f16, 2 per fp32 product (w_lo*x + w_hi*x, x rounded to f16)"}[precision],
                     "measured": f"HIP events on the launch stream, {n_prof} single-stream passes after the timed region"}
             ka = _lib.KERNEL_CLASSES.index("aggregate")
             if cnt[ka] > 0 and ms[ka] > 0:
@@ -349,7 +356,7 @@ def main():
             "metric": "rollout graph-steps/s (batch x rollout steps / wall; edge build + GNN forward + state update per graph-step)",
             "value": r["B_global"] * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_TOKEN[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {args.batch}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
                                    f"{args.material} {wl['n_obj']} particles, batch {args.batch}/GPU, {T}-step rollout",

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (csrc_sha)
 
 RUNS = [("rope", 256, 10, "fast"), ("rope", 256, 10, "f32"), ("granular", 128, 10, "fast"), ("cloth", 64, 20, "fast")]
-KERNELS = {"edge_encode": ("edge_encode_kernel", "edge_encode_nb_kernel"), "aggregate": ("aggregate_half_kernel", "aggregate_kernel"),
+KERNELS = {"edge_encode": ("edge_encode_kernel", "edge_encode_nb_kernel", "edge_encode_ws_kernel"), "aggregate": ("aggregate_half_kernel", "aggregate_kernel"),
            "node_update": ("node_update_kernel",), "node_encode": ("node_encode_kernel",)}
 
 
