@@ -1,8 +1,11 @@
-// ag_mlp.hip — fused dense-MLP kernels on the gfx950 matrix cores, two arithmetic modes:
+// ag_mlp.hip — fused dense-MLP kernels on the gfx950 matrix cores, three arithmetics:
 //   F32 : v_mfma_f32_32x32x2_f32   — exact fp32 (a k-ordered fmaf chain), 157 TFLOP/s class
 //   B3  : v_mfma_f32_32x32x16_bf16 — every fp32 operand split x = hi + lo (two bf16), products
 //         lo*hi + hi*lo + hi*hi accumulated in fp32 ("bf16x3"): ~2^-17 relative operand error, measured
 //         1e-6..6e-6 max-abs on the reference forwards (gate 1e-4), 16/3 = 5.3x the fp32 MFMA rate.
+//   H2  : v_mfma_f32_32x32x16_f16  — EDGE stack of precision mode 2 only: activations rounded to one fp16, weights split
+//         hi + lo (two fp16), lo*x + hi*x ("fp16x2", struct PrecH2); streaming kernel edge_encode_kernel<PrecH2> and the
+//         weight-stationary edge_encode_ws_kernel (the default: weights in registers, activations through LDS).
 //
 // Replaces the reference's Encoder / Propagator / ParticlePredictor stacks
 // (src/dynamics/gnn/model.py:4-60) and the one-hot gathers feeding them (model.py:214-253, 283-295).

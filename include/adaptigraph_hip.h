@@ -59,11 +59,16 @@ int ag_model_destroy(ag_model *m);
  *   "fuse_aggregate"   0/1/2 segment reduce as its own HBM-streaming kernel (0, default), inside node_update row-per-lane (1, slower),
  *                            or inside node_update through an LDS stage (2, precision 2 only: no `agg` table; measured equal solo, -4 % co-run)
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
- *   "edge_rows"        32/33/64  split-bf16 edge encoder variant: 32 = default kernel; 64 = two row blocks per wave, one workgroup per CU;
- *                            33 = 32 rows per wave on that kernel's pipeline (all bit-identical)
+ *   "edge_products"    2/3   precision 2 only: MFMAs per fp32 product in the EDGE stack: 2 = fp16 activations x split-fp16 weights (default;
+ *                            models whose edge weights exceed the fp16 range keep 3), 3 = split-bf16 like precision 1
+ *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
+ *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
+ *   "edge_rows"        32/33/34/64  split-bf16 edge encoder experiments (edge_products 3): 32 = r01 kernel; 64 = two row blocks per wave, one
+ *                            workgroup per CU; 33 = 32 rows per wave on that pipeline; 34 = eight waves sharing one ring (all bit-identical)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
  *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
- *                            2 = mode 1 + the per-edge Eterm table stored as fp16 (2e-6..1.1e-5) (default 2) */
+ *                            2 = mode 1 for the node-level stacks, the edge stack on two fp16 products per fp32 product and the per-edge
+ *                            Eterm table stored as fp16 (4e-6..9.4e-6) (default 2) */
 int ag_set_option(ag_model *m, const char *name, int value);
 
 /* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on

@@ -12,7 +12,7 @@ h16 = lambda x: x.half().double()
 b16 = lambda x: x.bfloat16().double()
 
 
-def forward(g, wq, xq, first, node=False):
+def forward(g, wq, xq, first, node=False, hsq=None, hrq=None):
     """wq / xq: rounding applied to the edge stack's weights / layer inputs (identity = exact); first: include layer 1."""
     t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).double()
     state, attrs, action, p_inst, phys = t("state"), t("attrs"), t("action"), t("p_instance"), t("phys")
@@ -36,7 +36,10 @@ def forward(g, wq, xq, first, node=False):
         eterm = lin(x, wrp[:, :150], brp, True)
         hcur = enc_n
         for _ in range(3):
-            eff = F.relu(eterm + lin(hcur, wrp[:, 150:300], None, node)[r] + lin(hcur, wrp[:, 300:], None, node)[s])
+            hr_t, hs_t = lin(hcur, wrp[:, 150:300], None, node), lin(hcur, wrp[:, 300:], None, node)
+            if hsq is not None: hs_t = hsq(hs_t)       # what an fp16 copy of the gathered sender table would cost
+            if hrq is not None: hr_t = hrq(hr_t)
+            eff = F.relu(eterm + hr_t[r] + hs_t[s])
             agg = torch.zeros(N, 150, dtype=torch.float64).index_add_(0, r, eff)
             hcur = F.relu(lin(enc_n, wpp[:, :150], bpp, node) + lin(agg, wpp[:, 150:], None, node) + hcur)
         x = hcur[:n_p]
@@ -53,6 +56,15 @@ cases = [("exact f64", ident, ident, True, False),
          ("B: x fp16, edge 2-4 + all node layers", ident, h16, False, True),
          ("A: W fp16, edge 2-4 + all node layers", h16, ident, False, True),
          ("x bf16, layers 2-4 (one product)", ident, b16, False, False)]
+extra = [("Hs (gathered sender terms) rounded to fp16", dict(hsq=h16)), ("Hr (receiver terms) rounded to fp16", dict(hrq=h16)),
+         ("B edge 1-4 + Eterm fp16 + Hs fp16", dict(hsq=h16))]
+for label, kw in extra[:2]:
+    errs = []
+    for name in golden_files("fwd_"):
+        g = load_golden(name)
+        if float(g["decoder_scale"]) != 1.0: continue
+        errs.append(f"{name[4:]} {np.abs(forward(g, ident, ident, True, False, **kw) - g['pred_motion']).max():.2e}")
+    print(f"{label:40s}", " | ".join(errs))
 for label, wq, xq, first, node in cases:
     errs = []
     for name in golden_files("fwd_"):
