@@ -1253,12 +1253,12 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 //
 // The streaming kernels above re-read the whole 320 KB weight image from L2 through LDS for every 128 edges: 2 560 B of
 // L2->LDS traffic and 2 560 B of LDS fragment reads per edge, against 388 B of HBM traffic; in the power-limited regime
-// this kernel runs in (DESIGN.md §9.1) that data movement is what is left to save (timing ablation of the streaming
-// kernel: 0.685 ms, 0.576 without the copies).  Here the dataflow is turned around:
+// this kernel runs in (DESIGN.md §9.3) that data movement is what is left to save (timing ablation of the streaming
+// kernel: 0.663 ms, 0.555 without the copies).  Here the dataflow is turned around:
 //  * ONE 256-thread workgroup per CU, one wave per SIMD, 512 registers per lane.  The four layers are cut into 15 "units"
 //    of one 32-feature out-tile (20 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
 //    80 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
-//    the whole launch — 1.2 MB of the CU's 2 MB register file hold the entire edge stack:
+//    the whole launch — 300 KB of the CU's 512 KB register file hold the entire edge stack:
 //        wave 0: first layer (its 20 KB of fragments in LDS), RE1 tiles 0-2      wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
 //        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: We tiles 1-4
 //    Three units of a wave sit in the accumulation half of the register file (the MFMA reads its A operand from there
@@ -1269,8 +1269,9 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 //  * One barrier per ROUND (80 MFMAs per wave), every buffer a ring of three blocks.  Round r: wave 1 loads the edge indices
 //    of its block i = r, the node rows of i-1 and writes the input features of i-2; the first layer works on i-3, RE1 on
 //    i-4, RE2 on i-6, We on i-8.
-//  * A lone wave hides an instruction only in the shadow of ONE MFMA (~7 issue slots per 32-cycle pass; s_memtime: a
-//    28-instruction epilogue queued behind four back-to-back MFMAs cost its full 110 cycles).  So the MFMAs are issued from
+//  * A lone wave hides an instruction only in the shadow of ONE MFMA, and only ~3 of them (tools/ubench/mfma_lone.hip: 32-33
+//    cycles per MFMA with <= 3 VALU instructions per MFMA, 39.5 with 4.5; s_memtime: a 28-instruction epilogue queued behind
+//    four back-to-back MFMAs cost its full 110 cycles).  So the MFMAs are issued from
 //    inline asm as (lo, hi) pairs of one accumulator, and after EACH pair runs one "micro-chore" of the previous phase's
 //    epilogue: two accumulator values -> ReLU -> one packed fp16 convert (every fourth: the 16-byte store), or one piece
 //    of the input gather, pinned by sched_barrier.  The accumulators a chore reads were last written four or more MFMAs
