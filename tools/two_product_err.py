@@ -12,7 +12,10 @@ h16 = lambda x: x.half().double()
 b16 = lambda x: x.bfloat16().double()
 
 
-def forward(g, wq, xq, first, node=False, hsq=None, hrq=None):
+def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None):
+    # groups: node-level layer groups whose INPUTS are rounded with xq: 'pe' particle_encoder, 'pp' particle_propagator (both
+    # column blocks), 'rs' W_r / W_s (relation_propagator node blocks), 'dec' non_rigid_predictor
+    G = lambda name: node or (groups is not None and name in groups)
     """wq / xq: rounding applied to the edge stack's weights / layer inputs (identity = exact); first: include layer 1."""
     t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).double()
     state, attrs, action, p_inst, phys = t("state"), t("attrs"), t("action"), t("p_instance"), t("phys")
@@ -27,7 +30,7 @@ def forward(g, wq, xq, first, node=False, hsq=None, hrq=None):
         n = int(g["n_rel"][b]); r = torch.from_numpy(g["recv"][b, :n].astype("int64")); s = torch.from_numpy(g["send"][b, :n].astype("int64"))
         rel = torch.cat([attrs[b, r], attrs[b, s], (grp[b, r] - grp[b, s]).abs().sum(1, keepdim=True), sn[b, r] - sn[b, s]], 1)
         x = p_in[b]
-        for i in (0, 2, 4): x = F.relu(lin(x, W[f"particle_encoder.model.{i}.weight"], W[f"particle_encoder.model.{i}.bias"], node))
+        for i in (0, 2, 4): x = F.relu(lin(x, W[f"particle_encoder.model.{i}.weight"], W[f"particle_encoder.model.{i}.bias"], G('pe')))
         enc_n = x
         x = rel
         for i in (0, 2, 4): x = F.relu(lin(x, W[f"relation_encoder.model.{i}.weight"], W[f"relation_encoder.model.{i}.bias"], first or i > 0))
@@ -36,16 +39,16 @@ def forward(g, wq, xq, first, node=False, hsq=None, hrq=None):
         eterm = lin(x, wrp[:, :150], brp, True)
         hcur = enc_n
         for _ in range(3):
-            hr_t, hs_t = lin(hcur, wrp[:, 150:300], None, node), lin(hcur, wrp[:, 300:], None, node)
+            hr_t, hs_t = lin(hcur, wrp[:, 150:300], None, G('rs')), lin(hcur, wrp[:, 300:], None, G('rs'))
             if hsq is not None: hs_t = hsq(hs_t)       # what an fp16 copy of the gathered sender table would cost
             if hrq is not None: hr_t = hrq(hr_t)
             eff = F.relu(eterm + hr_t[r] + hs_t[s])
             agg = torch.zeros(N, 150, dtype=torch.float64).index_add_(0, r, eff)
-            hcur = F.relu(lin(enc_n, wpp[:, :150], bpp, node) + lin(agg, wpp[:, 150:], None, node) + hcur)
+            hcur = F.relu(lin(enc_n, wpp[:, :150], bpp, G('pp')) + lin(agg, wpp[:, 150:], None, G('pp')) + hcur)
         x = hcur[:n_p]
-        x = F.relu(lin(x, W["non_rigid_predictor.linear_0.weight"], W["non_rigid_predictor.linear_0.bias"], node))
-        x = F.relu(lin(x, W["non_rigid_predictor.linear_1.weight"], W["non_rigid_predictor.linear_1.bias"], node))
-        out.append(lin(x, W["non_rigid_predictor.linear_2.weight"], W["non_rigid_predictor.linear_2.bias"], node))
+        x = F.relu(lin(x, W["non_rigid_predictor.linear_0.weight"], W["non_rigid_predictor.linear_0.bias"], G("dec")))
+        x = F.relu(lin(x, W["non_rigid_predictor.linear_1.weight"], W["non_rigid_predictor.linear_1.bias"], G("dec")))
+        out.append(lin(x, W["non_rigid_predictor.linear_2.weight"], W["non_rigid_predictor.linear_2.bias"], G("dec")))
     return torch.stack(out).numpy()
 
 
@@ -65,6 +68,13 @@ for label, kw in extra[:2]:
         if float(g["decoder_scale"]) != 1.0: continue
         errs.append(f"{name[4:]} {np.abs(forward(g, ident, ident, True, False, **kw) - g['pred_motion']).max():.2e}")
     print(f"{label:40s}", " | ".join(errs))
+for grp in ("pe", "pp", "rs", "dec"):
+    errs = []
+    for name in golden_files("fwd_"):
+        g = load_golden(name)
+        if float(g["decoder_scale"]) != 1.0: continue
+        errs.append(f"{name[4:]} {np.abs(forward(g, ident, h16, True, False, groups={grp}) - g['pred_motion']).max():.2e}")
+    print(f"{'B: x fp16, edge stack + node group ' + grp:40s}", " | ".join(errs))
 for label, wq, xq, first, node in cases:
     errs = []
     for name in golden_files("fwd_"):
