@@ -320,6 +320,11 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
     a.edge_rows = m->edge_rows;
     a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
     a.edge_ws = m->edge_ws;
+    {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
+        // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2: 128 -> 113.3 k, 192 -> 115.4 k, 256 -> 114.2 k)
+        const int full = m->max_blocks / AG_MLP_WG_PER_CU, share = max_blocks / AG_MLP_WG_PER_CU * 3 / 2;
+        a.ws_blocks = share < full ? (share > 0 ? share : 1) : (full > 0 ? full : 1);
+    }
     a.status = m->status;
     if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }

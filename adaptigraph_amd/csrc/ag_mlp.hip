@@ -2178,7 +2178,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     const dim3 block(AG_MLP_THREADS);
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
-            const int blocks = (a.e_cap + 31) / 32, slots = a.max_blocks / AG_MLP_WG_PER_CU;
+            const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
             hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), block, 0, s, w, a);
             return;
