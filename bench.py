@@ -16,7 +16,8 @@ Prints one JSON line on rank 0 (contract in the task statement) with
                 launch / average launch time, measured live with HIP events on the launch stream in a single-stream
                 pass, against the dense bf16/f16 MFMA peak (split modes) or the fp32 MFMA peak (f32 mode);
                 `mfma_issue_util` = the same with the 2 (mode "fast": f16 x split-f16) or 3 (split-bf16) MFMAs the edge stack
-                issues per fp32 product;
+                issues per fp32 product; `issue_frac_of_sustained` = issued FLOP/s against what pure MFMA chains sustain on random
+                operands under the chip's power limit (`sustained_peak_measured`, profiles/r02_power_probe.txt);
                 `traffic` = HBM bytes per launch from the PMC passes recorded in profiles/pmc_traffic.json, used only
                 if that file was collected from the kernel sources being run (sha256 of adaptigraph_amd/csrc), else null
   roofline_hbm  the segment-reduce kernel (HBM-bound), same accounting against 8 TB/s
@@ -51,6 +52,9 @@ from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+# what pure MFMA chains sustain on RANDOM operands under the ~1 300 W the chip regulates to (tools/power_probe.sh,
+# profiles/r02_power_probe.txt): the practical ceiling of an MFMA-bound kernel on real data; the f32 MFMA runs at full clock
+SUSTAINED_MFMA_TFLOPS = {"f32": 157.3, "bf16x3": 1777.0, "fast": 1630.0}
 PEAK_HBM_GBS = 8000.0                # HBM3E spec; 6290 GB/s is the measured float4-copy ceiling (same file)
 FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # F_min edge work: encoder 17->150->150->150 + W_rp[:, :150] block
 PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
@@ -253,6 +257,8 @@ class Engine:
             roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
                     "mfma_issue_util": EDGE_PRODUCTS[precision] * achieved / peak,
+                    "sustained_peak_measured": SUSTAINED_MFMA_TFLOPS[precision],
+                    "issue_frac_of_sustained": EDGE_PRODUCTS[precision] * achieved / SUSTAINED_MFMA_TFLOPS[precision],
                     "algorithmic_bytes": e_per * ((320 if precision == "fast" else 640) + 68),
                     "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": FLOP_PER_EDGE,
                     "mfma": {"f32": "v_mfma_f32_32x32x2_f32", "bf16x3": "v_mfma_f32_32x32x16_bf16, 3 per fp32 product (hi*hi + hi*lo + lo*hi)",
