@@ -147,7 +147,7 @@ def test_construct_graph_edges_match_reference(dataset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (2, 2e-3)])
+@pytest.mark.parametrize("precision,tol", [(0, 2e-5), (2, 2e-5)])    # measured (tools/evalrollout_dev.py): 1.2e-7 / 1.3e-6 on the error curves
 def test_rollout_dataset_matches_reference(dataset, weights, precision, tol):
     g, cfg, root = dataset
     cfg["dataset_config"]["device"] = DEV
@@ -183,4 +183,4 @@ def test_single_graph_signature_and_checkpoint_entry(dataset, weights):
     torch.save({k: torch.from_numpy(v) for k, v in weights.items()}, os.path.join(ck, "model_7.pth"))
     step_error = er.rollout(cfg, 7)
     assert os.path.exists(os.path.join(root, "rollout", "rollout-rope-model_7", "error_short.txt"))
-    assert np.abs(step_error - g["error_short"]).max() <= 2e-3      # default (fast) engine mode
+    assert np.abs(step_error - g["error_short"]).max() <= 2e-5      # default (fast) engine mode: measured 1.3e-6
