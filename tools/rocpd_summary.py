@@ -3,6 +3,7 @@
 
     python tools/rocpd_summary.py trace <trace_results.db>         # == rocprofv3 --kernel-trace --stats
     python tools/rocpd_summary.py pmc <pmc_results.db> [...]       # per-kernel counter sums / per-dispatch means
+    python tools/rocpd_summary.py streams <trace_results.db> [n]   # per-stream busy time / inter-kernel gaps over the LAST n launches
 """
 import sqlite3
 import sys
@@ -42,8 +43,32 @@ def pmc(paths):
                 print(f"    {c:32s} {acc[k][c] / cnt[k][c]:18.1f}")
 
 
+def streams(path, last=300):
+    """Are the rollout streams back-to-back?  Per stream (queue): busy time and the gaps between consecutive kernels over the
+    last `last` launches of the run (the timed region), then the listing of the first ~40 of them."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = list(cur.execute(f"select start, end, name, {qcol or '0'} from kernels order by start"))[-last:]
+    t0 = rows[0][0]
+    print(f"# window: {len(rows)} launches over {(rows[-1][1] - t0) / 1e3:.0f} us ({path})")
+    qs = sorted({r[3] for r in rows})
+    for q in qs:
+        mine = [r for r in rows if r[3] == q]
+        busy = sum(r[1] - r[0] for r in mine)
+        gaps = [max(0, b[0] - a[1]) for a, b in zip(mine[:-1], mine[1:])]
+        span = mine[-1][1] - mine[0][0]
+        print(f"# queue {q}: {len(mine)} launches, busy {busy / 1e3:.0f} us of {span / 1e3:.0f} ({100 * busy / max(span, 1):.0f} %), "
+              f"gaps: mean {sum(gaps) / max(len(gaps), 1) / 1e3:.2f} us, max {max(gaps or [0]) / 1e3:.1f} us, > 2 us: {sum(g > 2000 for g in gaps)}")
+    print("# start_us end_us dur_us queue kernel")
+    for st, en, n, q in rows[:40]:
+        print(f"{(st - t0) / 1e3:9.1f} {(en - t0) / 1e3:9.1f} {(en - st) / 1e3:8.1f}  q{qs.index(q)} {short(n)[:40]}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "streams":
+        streams(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 300)
     else:
         pmc(sys.argv[2:])
