@@ -87,11 +87,44 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
 }
 
+
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_aggregate_stream.inc"
+#endif
+
 }  // namespace
+#if defined(AG_EXPERIMENTS) && AGS_TRACE
+extern "C" int ag_debug_agg_trace(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ags_trace), sizeof(ags_trace)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ags_trace), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s)
 {
     const int nodes = a.B * a.N;
+#ifdef AG_EXPERIMENTS
+    if (a.eterm_half && a.agg_stream && (size_t)nodes * AG_FP * sizeof(float) < (1ull << 32)) {
+        int grid = (a.max_blocks > 0 ? a.max_blocks : 512) / AG_MLP_WG_PER_CU * AGS_WGPC;     // a.max_blocks = this launch's share of the chip, in MLP workgroups (2 per CU)
+        int per = (nodes + grid - 1) / grid;
+#ifdef AGS_NODES
+        per = AGS_NODES;
+#endif
+        if (per < 3 * AGS_W) per = 3 * AGS_W;
+        grid = (nodes + per - 1) / per;
+        hipLaunchKernelGGL(aggregate_stream_kernel, dim3(grid), dim3(64 * (AGS_W + 1)), 0, s, a, per);
+        return;
+    }
+#ifdef AGP_ON
+    if (a.eterm_half) {
+        const int nblk = (nodes + kNodesPerBlockH - 1) / kNodesPerBlockH;
+        hipLaunchKernelGGL(aggregate_half_range_kernel, dim3((nblk + AGP_BLOCKS - 1) / AGP_BLOCKS), dim3(256), 0, s, a);
+        return;
+    }
+#endif
+#endif   // AG_EXPERIMENTS
     if (a.eterm_half) {
         hipLaunchKernelGGL(aggregate_half_kernel, dim3((nodes + kNodesPerBlockH - 1) / kNodesPerBlockH), dim3(256), 0, s, a);
         return;

@@ -155,6 +155,7 @@ struct ag_model {
     int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
+    int agg_stream = 0;         // experiment builds only (-DAG_EXPERIMENTS, csrc/experiments/): 1 = LDS-DMA streamed segment reduce (measured slower)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -320,6 +321,7 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
     a.edge_rows = m->edge_rows;
     a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
     a.edge_ws = m->edge_ws;
+    a.agg_stream = m->agg_stream;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
         // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2: 128 -> 113.3 k, 192 -> 115.4 k, 256 -> 114.2 k)
         const int full = m->max_blocks / AG_MLP_WG_PER_CU, share = max_blocks / AG_MLP_WG_PER_CU * 3 / 2;
@@ -380,6 +382,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
+    if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -610,6 +613,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
+    else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
     else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;

@@ -78,6 +78,7 @@ struct AgFwdArgs {
     int edge_products; // precision mode 2 only: 2 = fp16 activations x split-fp16 weights in the edge stack (default), 3 = split-bf16 like mode 1
     int ws_blocks;     // workgroups of the weight-stationary edge encoder for this launch
     int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
+    int agg_stream;    // precision mode 2: 1 = streamed segment reduce (aggregate_stream_kernel: Eterm rows + sender indices through an LDS-DMA ring, default), 0 = aggregate_half_kernel
     int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
                        // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };

@@ -351,26 +351,13 @@ __global__ __launch_bounds__(256) void select_cells_kernel(AgEdgeArgs a)
 // its own receiver and keeps its K best (d, j) in registers (compare-exchange insertion), so 64 receivers are in
 // flight per wave instead of one — the wave-per-receiver kernel above is a chain of dependent round trips per row.
 template <int K>
-__global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
+__device__ __forceinline__ int lanes_exact(bool active, float xi, float yi, float zi, bool ti, const GridParams &g, const int32_t *cstart,
+                                           const float4 *sorted, float thr, float (&bd)[K], int (&bj)[K])
 {
-    const int b = blockIdx.y, N = a.N;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float *pos = a.pos + (size_t)b * a.pos_stride;
-    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
-    const GridParams g = reinterpret_cast<const GridParams *>(a.grid_raw)[b];
-    const int32_t *cstart = a.cell_start + (size_t)b * (kCellMax + 1);
-    const float4 *sorted = a.sorted + (size_t)b * N;
-    const float thr = a.thr_sq[b];
-    const size_t row = (size_t)b * N + i;
-    const bool mi = mk[i], ti = tl[i];
-    float bd[K];
-    int bj[K];
 #pragma unroll
     for (int s = 0; s < K; ++s) { bd[s] = 3.0e38f; bj[s] = 0x7fffffff; }
     int cnt = 0;
-    if (mi) {
-        const float xi = pos[i * 3], yi = pos[i * 3 + 1], zi = pos[i * 3 + 2];
+    if (active) {
         const int ix = cell_coord(xi, g.x0, g.inv, g.nx), iy = cell_coord(yi, g.y0, g.inv, g.ny), iz = cell_coord(zi, g.z0, g.inv, g.nz);
         const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
         for (int r = 0; r < 9; ++r) {
@@ -402,6 +389,27 @@ __global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
             }
         }
     }
+    return cnt;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
+{
+    const int b = blockIdx.y, N = a.N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float *pos = a.pos + (size_t)b * a.pos_stride;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    const GridParams g = reinterpret_cast<const GridParams *>(a.grid_raw)[b];
+    const int32_t *cstart = a.cell_start + (size_t)b * (kCellMax + 1);
+    const float4 *sorted = a.sorted + (size_t)b * N;
+    const float thr = a.thr_sq[b];
+    const size_t row = (size_t)b * N + i;
+    const bool mi = mk[i], ti = tl[i];
+    float bd[K];
+    int bj[K];
+    const float xi = mi ? pos[i * 3] : 0.f, yi = mi ? pos[i * 3 + 1] : 0.f, zi = mi ? pos[i * 3 + 2] : 0.f;
+    const int cnt = lanes_exact<K>(mi, xi, yi, zi, ti, g, cstart, sorted, thr, bd, bj);
     bool hit = false;
 #pragma unroll
     for (int s = 0; s < K; ++s)
@@ -411,6 +419,102 @@ __global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
             for (int t = 0; t < K; ++t) rank += (t < cnt && bj[t] < bj[s]) ? 1 : 0;
             a.sel0[row * a.cap0 + rank] = bj[s];        // ascending sender index
             hit = hit || (ti && !tl[bj[s]]);
+        }
+    a.deg[row] = cnt;
+    if (a.connect && a.variant == 1 && hit) atomicOr(&a.flag[b], 1);   // batch_mask (graph.py:123,135)
+}
+
+// The same search for large K (top-k 20, the granular configuration), where the insertion network IS the cost: ~40 in-radius
+// candidates per receiver x 20 compare-exchange steps x 7 VALU ops, executed by the whole wave whenever any lane accepts.
+//  * keys are ONE 32-bit word, (fp32 bits of d, sign bit dropped, low `jb` bits cleared) | j, so a compare-exchange step is
+//    v_min_u32 + v_max_u32 (2 ops instead of 7).  Truncating d is monotone, so the K smallest keys are the K nearest senders
+//    EXACTLY unless the K-th and (K+1)-th candidates agree in every kept bit of d; the network therefore carries K+1 entries
+//    and a receiver whose boundary is ambiguous is redone with the exact (d, j) network (a fraction of a percent of the
+//    receivers at N ~ 2k: d keeps 20 bits).  The in-radius test itself is made on the full fp32 d.
+//  * receivers are taken in CELL order (thread t = t-th binned particle), so the lanes of a wave walk the same cell ranges:
+//    equal trip counts and broadcast candidate loads instead of 64 unrelated walks.
+// Results are bit-identical to select_lanes_kernel / the brute-force scan (tests compare all paths with the oracle).
+template <int K>
+__global__ __launch_bounds__(256) void select_lanes_packed_kernel(AgEdgeArgs a, int jb)
+{
+    const int b = blockIdx.y, N = a.N;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    if (t < N && !mk[t]) a.deg[(size_t)b * N + t] = 0;            // receivers that were not binned have no edges
+    const GridParams g = reinterpret_cast<const GridParams *>(a.grid_raw)[b];
+    const int32_t *cstart = a.cell_start + (size_t)b * (kCellMax + 1);
+    const float4 *sorted = a.sorted + (size_t)b * N;
+    const float thr = a.thr_sq[b];
+    const bool active = t < g.total;
+    const float4 me = active ? sorted[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wi = __float_as_int(me.w);
+    const int i = wi & 0x3fffffff;
+    const bool ti = (wi & 0x40000000) != 0;
+    const float xi = me.x, yi = me.y, zi = me.z;
+    const unsigned jmask = (1u << jb) - 1u;
+    unsigned kl[K + 1];
+#pragma unroll
+    for (int s = 0; s <= K; ++s) kl[s] = 0xffffffffu;
+    int tot = 0;
+    if (active) {
+        const int ix = cell_coord(xi, g.x0, g.inv, g.nx), iy = cell_coord(yi, g.y0, g.inv, g.ny), iz = cell_coord(zi, g.z0, g.inv, g.nz);
+        const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
+        for (int r = 0; r < 9; ++r) {
+            const int z2 = iz + r / 3 - 1, y2 = iy + r % 3 - 1;
+            if (z2 < 0 || z2 >= g.nz || y2 < 0 || y2 >= g.ny) continue;
+            const int base = (z2 * g.ny + y2) * g.nx;
+            const int p1 = cstart[base + x_hi + 1];
+            for (int p = cstart[base + x_lo]; p < p1; ++p) {
+                const float4 sj = sorted[p];
+                const int w = __float_as_int(sj.w);
+                const float dx = xi - sj.x, dy = yi - sj.y, dz = zi - sj.z;
+                float d = (dx * dx + dy * dy) + dz * dz;
+                if (ti && (w & 0x40000000)) d = 1e10f;
+                if ((d - thr) < 0.0f) {
+                    unsigned key = ((__float_as_uint(d) << 1) & ~jmask) | (unsigned)(w & 0x3fffffff);
+#pragma unroll
+                    for (int s = 0; s <= K; ++s) {
+                        const unsigned lo = min(kl[s], key);
+                        key = max(kl[s], key);
+                        kl[s] = lo;
+                    }
+                    ++tot;
+                }
+            }
+        }
+    }
+    int cnt = tot < K ? tot : K;
+    const bool ambiguous = tot > K && ((kl[K - 1] ^ kl[K]) & ~jmask) == 0u;
+    if (__ballot(ambiguous)) {          // rare: the exact network for those lanes (the others idle through it)
+        float bd[K];
+        int bj[K];
+        const int c2 = lanes_exact<K>(ambiguous, xi, yi, zi, ti, g, cstart, sorted, thr, bd, bj);
+        if (ambiguous) {
+            cnt = c2;
+#pragma unroll
+            for (int s = 0; s < K; ++s) kl[s] = (unsigned)bj[s];
+        }
+    }
+    // senders in ascending index order: odd-even transposition sort of the K sender ids (unused slots sort to the end)
+    unsigned js[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) js[s] = s < cnt ? (kl[s] & (ambiguous ? 0x7fffffffu : jmask)) : 0x7fffffffu;
+#pragma unroll
+    for (int round = 0; round < K; ++round)
+#pragma unroll
+        for (int s = round & 1; s + 1 < K; s += 2) {
+            const unsigned lo = min(js[s], js[s + 1]), hi = max(js[s], js[s + 1]);
+            js[s] = lo;
+            js[s + 1] = hi;
+        }
+    if (!active) return;
+    const size_t row = (size_t)b * N + i;
+    bool hit = false;
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+        if (s < cnt) {
+            a.sel0[row * a.cap0 + s] = (int)js[s];
+            hit = hit || (ti && !tl[js[s]]);
         }
     a.deg[row] = cnt;
     if (a.connect && a.variant == 1 && hit) atomicOr(&a.flag[b], 1);   // batch_mask (graph.py:123,135)
@@ -580,7 +684,13 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
         const dim3 lgrid((a.N + 255) / 256, a.B);
         if (a.cap0 == 5 && a.topk == 5) hipLaunchKernelGGL(select_lanes_kernel<5>, lgrid, dim3(256), 0, s, a);
         else if (a.cap0 == 10 && a.topk == 10) hipLaunchKernelGGL(select_lanes_kernel<10>, lgrid, dim3(256), 0, s, a);
-        else if (a.cap0 == 20 && a.topk == 20) hipLaunchKernelGGL(select_lanes_kernel<20>, lgrid, dim3(256), 0, s, a);
+        else if (a.cap0 == 20 && a.topk == 20) {
+            static const int packed = getenv("AG_EDGE_PACKED") ? atoi(getenv("AG_EDGE_PACKED")) : 1;      // 0: the exact (d, j) network for every receiver
+            int jb = 1;
+            while ((1 << jb) < a.N) ++jb;
+            if (packed && jb <= 16) hipLaunchKernelGGL(select_lanes_packed_kernel<20>, lgrid, dim3(256), 0, s, a, jb);
+            else hipLaunchKernelGGL(select_lanes_kernel<20>, lgrid, dim3(256), 0, s, a);
+        }
         else hipLaunchKernelGGL(select_cells_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), 0, s, a);
     } else {
         const int Np = (a.N + 63) & ~63;

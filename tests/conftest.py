@@ -24,6 +24,36 @@ def weights():
     return {k: d[k] for k in d.files}
 
 
+def rescale_edge_stack(sd, s):
+    """Power-of-two, function-preserving rescale of the relation encoder (ReLU is positively homogeneous): layer l's weights
+    x s and bias x s^(l+1), W_rp[:, :F] / s^3 -- the reference computes the same function, the engine's edge-stack activations
+    are s, s^2, s^3 times larger (fp16 range stress of precision mode 2; tools/gen_trained.py made the goldens this way)."""
+    out = {k: v.copy() for k, v in sd.items()}
+    F = out["relation_encoder.model.4.weight"].shape[0]
+    for li, k in enumerate((0, 2, 4)):
+        out[f"relation_encoder.model.{k}.weight"] *= s
+        out[f"relation_encoder.model.{k}.bias"] *= s ** (li + 1)
+    out["relation_propagator.linear.weight"][:, :F] /= s ** 3
+    return out
+
+
+_WEIGHTS = {}
+
+
+def weights_for(g, default):
+    """The 22-tensor state_dict a golden was generated with: seed-0 default init unless the fixture names a trained set
+    (`weights`, tools/gen_trained.py) and possibly an edge-stack rescale factor (`edge_rescale`)."""
+    import numpy as np
+    if "weights" not in g:
+        return default
+    name, s = str(g["weights"]), float(g["edge_rescale"]) if "edge_rescale" in g else 1.0
+    if (name, s) not in _WEIGHTS:
+        d = np.load(os.path.join(GOLDEN, name + ".npz"))
+        sd = {k: d[k] for k in d.files}
+        _WEIGHTS[(name, s)] = sd if s == 1.0 else rescale_edge_stack(sd, s)
+    return _WEIGHTS[(name, s)]
+
+
 def load_golden(name):
     import numpy as np
     d = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, load_golden
+from conftest import golden_files, load_golden, weights_for
 from adaptigraph_amd import _lib, configs, synth
 from adaptigraph_amd import graph as aggraph
 from adaptigraph_amd.forward_dynamics import dynamics, dynamics_masked, rollout
@@ -113,6 +113,36 @@ def test_edges_vs_oracle_exact(material, n_obj, batch, variant, kw):
         assert np.array_equal(r, recv[b, :n_rel[b]]) and np.array_equal(s, send[b, :n_rel[b]]), f"sample {b}"
 
 
+@pytest.mark.parametrize("n_obj,seed", [(300, 1), (2000, 2), (5000, 3)])
+def test_edges_topk20_packed_key_boundary_vs_oracle(n_obj, seed):
+    """Top-k 20 (granular) takes the packed-key selection kernel (csrc/ag_edges.hip select_lanes_packed_kernel): 32-bit keys that
+    keep only the leading bits of d.  Clouds built to make the K-th / (K+1)-th candidates (nearly) indistinguishable in those
+    bits -- rings of ~45 senders at the same distance up to a few ulps around every centre, exact duplicates (equal d: the tie
+    goes to the lower sender index), and a plain dense blob -- must still give the oracle's edge lists bit for bit."""
+    rng = np.random.default_rng(seed)
+    n_c = max(n_obj // 50, 1)
+    centres = rng.uniform(0, 1.0 * np.sqrt(n_c), (n_c, 2))
+    pts = []
+    for c in centres:
+        m = 45
+        ang = rng.uniform(0, 2 * np.pi, m)
+        rad = 0.3 * (1 + rng.integers(-3, 4, m) * 6e-8)              # a handful of ulps around r = 0.3
+        pts.append(np.stack([c[0] + rad * np.cos(ang), np.zeros(m), c[1] + rad * np.sin(ang)], 1))
+        pts.append(np.array([[c[0], 0.0, c[1]]]))
+    pts = np.concatenate(pts)[:n_obj]
+    if len(pts) < n_obj:
+        pts = np.concatenate([pts, rng.uniform(0, 0.5, (n_obj - len(pts), 3)) * [1, 0.05, 1]])
+    pts[n_obj // 3: n_obj // 3 + 20] = pts[0]                         # exact duplicates
+    g = synth.make_graph_inputs("granular", n_obj, 2, seed=seed)
+    pos = g["state"][:, -1].copy()
+    pos[0, :n_obj] = pts.astype(np.float32)
+    n_rel, recv, send = ago.build_edges(pos, 0.4, g["mask"], g["tool_mask"], 20, False, "batch")
+    csr = aggraph.build_edges(t(pos), 0.4, t(g["mask"]), t(g["tool_mask"]), 20, False, "batch", max_tools=g["n_tools"])
+    assert csr.n_rel().cpu().tolist() == n_rel.tolist()
+    for b, (r, s_) in enumerate(csr.to_lists()):
+        assert np.array_equal(r, recv[b, :n_rel[b]]) and np.array_equal(s_, send[b, :n_rel[b]]), f"sample {b}"
+
+
 def test_edges_dropin_dense_signature():
     g = load_golden("edges_rope64_batch")
     Rr, Rs = aggraph.construct_edges_from_states_batch(t(g["pos"]), 0.5, t(g["mask"]), t(g["tool_mask"]), topk=10,
@@ -135,7 +165,7 @@ def test_edges_dropin_dense_signature():
 def test_forward_golden(name, weights, prec):
     g = load_golden(name)
     material = str(g["material"])
-    m = make_model(weights, material, float(g["decoder_scale"]), prec)
+    m = make_model(weights_for(g, weights), material, float(g["decoder_scale"]), prec)
     N = g["attrs"].shape[1]
     csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
     kw = {material + "_physics_param": t(g["phys"])}
@@ -143,6 +173,7 @@ def test_forward_golden(name, weights, prec):
     scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
     assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC[prec] * scale
     assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= TOL_BY_PREC[prec] * scale
+    assert m.take_status() == 0, "no fp16 overflow / non-finite sum on any golden (ag_model_status)"
 
 
 def test_forward_dense_onehot_inputs_dropin(weights, model, prec):
@@ -428,8 +459,10 @@ def explain_divergence(model, weights, material, state, action, b, state_mask=No
 def test_dynamics_golden(name, weights, prec):
     g = load_golden(name)
     material = str(g["material"])
+    weights = weights_for(g, weights)
     m = make_model(weights, material, prec=prec)
     out = dynamics(t(g["state"]), t(g["action"]), m, DEV, _ppm(material))
+    assert m.take_status() == 0
     assert out["state_seqs"].shape == g["state_seqs"].shape
     assert np.abs(out["action_seqs"].cpu().numpy() - g["action_seqs"]).max() <= 1e-6
     err = np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).reshape(g["state_seqs"].shape[0], -1).max(1)

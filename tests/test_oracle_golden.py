@@ -6,7 +6,7 @@ SURVEY.md §8c: the reference has no tests of its own for this path, so these fi
 import numpy as np
 import pytest
 
-from conftest import golden_files, load_golden
+from conftest import golden_files, load_golden, weights_for
 from adaptigraph_amd import configs
 from oracle import ag_oracle as ago
 
@@ -28,7 +28,7 @@ def test_edges_exact(name):
 @pytest.mark.parametrize("name", golden_files("fwd_"))
 def test_forward(name, weights):
     g = load_golden(name)
-    w = dict(weights)
+    w = dict(weights_for(g, weights))
     s = float(g["decoder_scale"])
     if s != 1.0:
         w["non_rigid_predictor.linear_2.weight"] = w["non_rigid_predictor.linear_2.weight"] * np.float32(s)
@@ -75,7 +75,7 @@ def test_decode_action(name):
 def test_dynamics(name, weights):
     g = load_golden(name)
     task = configs.task_config(str(g["material"]))
-    seq, dec = ago.dynamics(weights, task, g["state"], g["action"])
+    seq, dec = ago.dynamics(weights_for(g, weights), task, g["state"], g["action"])
     assert np.abs(dec - g["action_seqs"]).max() <= 1e-6
     assert np.abs(seq - g["state_seqs"]).max() <= 1e-4
 

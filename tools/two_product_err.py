@@ -6,13 +6,17 @@ import numpy as np, torch
 import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import load_golden, golden_files
-W = {k: torch.from_numpy(v).double() for k, v in load_golden("weights_seed0").items()}
+from conftest import load_golden, golden_files, weights_for
+W0 = load_golden("weights_seed0")
+W = {}
+def use_weights(g):        # per golden: seed-0 default init, or the trained set the fixture names (tools/gen_trained.py)
+    W.clear(); W.update({k: torch.from_numpy(v).double() for k, v in weights_for(g, W0).items()})
 h16 = lambda x: x.half().double()
 b16 = lambda x: x.bfloat16().double()
 
 
-def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None):
+def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None, etq=None):
+    use_weights(g)
     # groups: node-level layer groups whose INPUTS are rounded with xq: 'pe' particle_encoder, 'pp' particle_propagator (both
     # column blocks), 'rs' W_r / W_s (relation_propagator node blocks), 'dec' non_rigid_predictor
     G = lambda name: node or (groups is not None and name in groups)
@@ -37,6 +41,7 @@ def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None):
         wrp, brp = W["relation_propagator.linear.weight"], W["relation_propagator.linear.bias"]
         wpp, bpp = W["particle_propagator.linear.weight"], W["particle_propagator.linear.bias"]
         eterm = lin(x, wrp[:, :150], brp, True)
+        if etq is not None: eterm = etq(eterm)          # the per-edge table as stored (fp16 in precision mode 2)
         hcur = enc_n
         for _ in range(3):
             hr_t, hs_t = lin(hcur, wrp[:, 150:300], None, G('rs')), lin(hcur, wrp[:, 300:], None, G('rs'))
@@ -58,7 +63,8 @@ cases = [("exact f64", ident, ident, True, False),
          ("B: x fp16, layers 1-4", ident, h16, True, False), ("B: x fp16, layers 2-4", ident, h16, False, False),
          ("B: x fp16, edge 2-4 + all node layers", ident, h16, False, True),
          ("A: W fp16, edge 2-4 + all node layers", h16, ident, False, True),
-         ("x bf16, layers 2-4 (one product)", ident, b16, False, False)]
+         ("x bf16, layers 2-4 (one product)", ident, b16, False, False),
+         ("C: W fp16 AND x fp16 (ONE product), 1-4", h16, h16, True, False)]
 extra = [("Hs (gathered sender terms) rounded to fp16", dict(hsq=h16)), ("Hr (receiver terms) rounded to fp16", dict(hrq=h16)),
          ("B edge 1-4 + Eterm fp16 + Hs fp16", dict(hsq=h16))]
 for label, kw in extra[:2]:
@@ -81,4 +87,12 @@ for label, wq, xq, first, node in cases:
         g = load_golden(name)
         if float(g["decoder_scale"]) != 1.0: continue
         errs.append(f"{name[4:]} {np.abs(forward(g, wq, xq, first, node) - g['pred_motion']).max():.2e}")
+    print(f"{label:40s}", " | ".join(errs))
+# the shipped mode 2 and the one-product candidate, both WITH the fp16 per-edge table (what the engine would actually compute)
+for label, wq, xq in (("mode 2 as shipped: B 1-4 + Eterm fp16", ident, h16), ("ONE product: C 1-4 + Eterm fp16", h16, h16)):
+    errs = []
+    for name in golden_files("fwd_"):
+        g = load_golden(name)
+        if float(g["decoder_scale"]) != 1.0: continue
+        errs.append(f"{name[4:]} {np.abs(forward(g, wq, xq, True, False, etq=h16) - g['pred_motion']).max():.2e}")
     print(f"{label:40s}", " | ".join(errs))
