@@ -148,7 +148,6 @@ struct ag_model {
     int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3|fast / ag_set_option("precision", 0|1|2)
     int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
-    double eterm_row_l1 = 0.0;  // max_o sum_k |W_rp[o, k]|, k < nf (bound used by the fp16 Eterm guard)
     int edge_products = 2;      // precision mode 2: edge stack on two fp16 products per k16-step (fp16 activations x split-fp16 weights);
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
@@ -214,17 +213,6 @@ int pack_and_upload(ag_model *m, const float *const *t)
         AG_HIP(hipDeviceSynchronize());
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
-    // fp16 Eterm table (precision mode 2): |Eterm| <= ||W_e row||_1 * max|enc_e| + |b|.  The table saturates at 65504;
-    // record a conservative row-norm bound so that mode 2 can be refused for checkpoints whose per-edge term could overflow.
-    {
-        double worst = 0.0;
-        for (int o = 0; o < F; ++o) {
-            double l1 = 0.0;
-            for (int k = 0; k < F; ++k) l1 += fabs((double)t[W_RP][(size_t)o * 3 * F + k]);
-            worst = l1 > worst ? l1 : worst;
-        }
-        m->eterm_row_l1 = worst;
-    }
     // two-product fp16 edge stack (precision mode 2): only if every edge-stack weight and bias is representable in fp16
     {
         bool ok = true;

@@ -780,8 +780,12 @@ struct PrecB3 {
 // What it buys: the edge encoder is power-limited (pure bf16 MFMA chains on random data sustain 1.78 PF at
 // 1 300 W, fp16 chains 1.63 PF), so the only lever is fewer MFMAs: 320 instead of 480 per 32 edges, one convert instead of a
 // 6-op hi/lo split per value pair, and half the operand registers (three workgroups per CU instead of two).
-// An activation beyond +-65504 converts to inf, reaches Eterm as inf/NaN and raises the model's sticky status bit in the
-// segment reduce, exactly like an Eterm overflow (ag_model_status).
+// RANGE: a hidden activation beyond +-65504 converts to +inf.  That is reported only when it survives to the per-edge table as a
+// non-finite value (ag_model_status): inf x negative weight = -inf, and the one-op ReLU (an integer max) turns -inf and
+// sign-bit NaNs into 0, so an overflow CAN be swallowed by the next hidden layer.  The status word is therefore a detector of
+// Eterm overflow, not a guarantee for the hidden activations: for checkpoints with an unknown activation range use precision 1
+// (split-bf16, fp32 range).  Measured head-room: the trained goldens rescaled to 64x larger edge-stack activations
+// (tests/golden/*act64*, tools/gen_trained.py) still match within the mode's tolerance with status 0.
 struct PrecH2 {
     struct Act { f16x8 v[2 * AG_NT]; };
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)

@@ -2,8 +2,8 @@
 
 `running_cost` is a drop-in for src/planning/plan.py:27-59; `MPPIPlanner.trajectory_optimization_mppi` follows
 src/planning/real_world/planner.py:234-277 (sample -> rollout -> evaluate -> softmax update -> keep the best sample),
-with the rollout sharded over the ranks of the process group when one is initialised.  Everything stays on the GPU:
-the only host read per iteration is the `error.max()` normaliser the reference also reads.
+with the rollout sharded over the ranks of the process group when one is initialised.  Everything stays on the GPU: an
+iteration has no host read at all (the reference's `error.max().item()` normaliser is a 0-d tensor here).
 """
 import functools
 
@@ -19,7 +19,7 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox, **kwa
     """state (bsz, L, n, 3), action (bsz, L, 4), state_cur (n, 3), bbox [[xmin,xmax],[zmin,zmax]] -> {"reward_seqs": (bsz,)}."""
     bsz, L = state.shape[0], state.shape[1]
     error = error_func(state.reshape(bsz * L, state.shape[2], state.shape[3])).reshape(bsz, L)
-    error_weight = 2.0 / (error.max().item() + 1e-6)
+    error_weight = 2.0 / (error.max() + 1e-6)                # a 0-d tensor: the reference reads it back to the host (plan.py:38), the engine need not
     collision = penalty_func(state, action, state_cur)
     lo, hi = state.min(dim=2).values, state.max(dim=2).values                     # (bsz, L, 3)
     bbox = torch.as_tensor(bbox, dtype=state.dtype, device=state.device)
@@ -29,11 +29,115 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox, **kwa
     return {"reward_seqs": reward}
 
 
+class Planner:
+    """Drop-in for the MPPI branch of the reference's `Planner(config)` (src/planning/real_world/planner.py:38-326): the same
+    config keys, `trajectory_optimization(state_cur, act_seq)` result dict and `merge_res`, so plan.py:190-247 can construct it
+    unchanged with `model_rollout_fn = partial(adaptigraph_amd.forward_dynamics.dynamics, model=..., ...)`.
+
+    Required keys: action_dim, model_rollout_fn, evaluate_traj_fn, n_sample, n_look_ahead, n_update_iter, reward_weight,
+    action_lower_lim, action_upper_lim (tensors of shape (action_dim,)), planner_type ('MPPI'; 'GD' differentiates through the
+    rollout, which the inference engine does not provide, and 'MPPI_GD' is unimplemented in the reference too).
+    Optional keys (reference defaults): device 'cuda', verbose False, sampling_action_seq_fn, clip_action_seq_fn,
+    optimize_action_mppi_fn, noise_type 'normal', noise_level 0.1, n_his 1, rollout_best True.
+    The per-iteration progress print of the reference is dropped; nothing here reads a value back to the host."""
+
+    def __init__(self, config):
+        self.config = config
+        self.action_dim = config["action_dim"]
+        self.model_rollout, self.evaluate_traj = config["model_rollout_fn"], config["evaluate_traj_fn"]
+        self.n_sample, self.n_look_ahead, self.n_update_iter = config["n_sample"], config["n_look_ahead"], config["n_update_iter"]
+        self.reward_weight = config["reward_weight"]
+        self.action_lower_lim, self.action_upper_lim = config["action_lower_lim"], config["action_upper_lim"]
+        self.planner_type = config["planner_type"]
+        assert self.planner_type in ("GD", "MPPI", "MPPI_GD")
+        assert isinstance(self.action_lower_lim, torch.Tensor) and isinstance(self.action_upper_lim, torch.Tensor)
+        assert self.action_lower_lim.shape == (self.action_dim,) and self.action_upper_lim.shape == (self.action_dim,)
+        self.device = config.get("device", "cuda")
+        self.verbose = config.get("verbose", False)
+        self.sample_action_sequences = config.get("sampling_action_seq_fn", self.sample_action_sequences_default)
+        self.clip_action_sequences = config.get("clip_action_seq_fn", self.clip_actions_default)
+        self.optimize_action_mppi = config.get("optimize_action_mppi_fn", self.optimize_action_mppi_default)
+        self.noise_type = config.get("noise_type", "normal")
+        assert self.noise_type == "normal", "only the 'normal' sampler is provided (the 'fps' grid sampler needs the reference's fps_np)"
+        self.noise_level = config.get("noise_level", 0.1)
+        self.n_his = config.get("n_his", 1)
+        self.rollout_best = config.get("rollout_best", True)
+        self.chunk_id, self.total_chunks = 0, 1
+
+    def sample_action_sequences_default(self, act_seq, iter_index=0):
+        """Low-pass filtered Gaussian perturbations of `act_seq` (planner.py:119-160: beta = 0.7), clipped per step."""
+        assert act_seq.shape == (self.n_look_ahead, self.action_dim)
+        acts = act_seq[None].repeat(self.n_sample, 1, 1)
+        resid = torch.zeros((self.n_sample, self.action_dim), dtype=acts.dtype, device=self.device)
+        for i in range(self.n_look_ahead):
+            noise = torch.normal(0, self.noise_level, (self.n_sample, self.action_dim), device=self.device)
+            resid = 0.7 * noise + resid * (1.0 - 0.7)
+            acts[:, i] = torch.clamp(acts[:, i] + resid, self.action_lower_lim, self.action_upper_lim)
+        return acts
+
+    def clip_actions_default(self, act_seqs):
+        act_seqs.data.clamp_(self.action_lower_lim, self.action_upper_lim)
+        return act_seqs
+
+    def optimize_action_mppi_default(self, act_seqs, reward_seqs):
+        w = torch.softmax(reward_seqs * self.reward_weight, dim=0)
+        return self.clip_action_sequences((act_seqs * w[:, None, None]).sum(dim=0))
+
+    def optimize_action(self, act_seqs, reward_seqs, optimizer=None):
+        assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim) and reward_seqs.shape == (self.n_sample,)
+        if self.planner_type != "MPPI":
+            raise NotImplementedError(f"planner_type {self.planner_type}: only the MPPI update is provided")
+        return self.optimize_action_mppi(act_seqs, reward_seqs)
+
+    def trajectory_optimization(self, state_cur, act_seq):
+        assert isinstance(state_cur, torch.Tensor) and isinstance(act_seq, torch.Tensor)
+        assert act_seq.shape == (self.n_look_ahead, self.action_dim)
+        if self.planner_type != "MPPI":
+            raise NotImplementedError(f"planner_type {self.planner_type}: the engine rolls out without autograd; use 'MPPI'")
+        return self.trajectory_optimization_mppi(state_cur, act_seq)
+
+    @torch.no_grad()
+    def trajectory_optimization_mppi(self, state_cur, act_seq):
+        model_outputs, eval_outputs = [], []
+        best_seq = best_reward = None
+        for i in range(self.n_update_iter):
+            act_seqs = self.sample_action_sequences(act_seq, iter_index=i)
+            assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim)
+            model_out = self.model_rollout(state_cur, act_seqs)
+            eval_out = self.evaluate_traj(model_out["state_seqs"], act_seqs, state_cur=state_cur, weights=model_out.get("weights"))
+            reward = eval_out["reward_seqs"]
+            act_seq = self.optimize_action(act_seqs, reward)
+            k = torch.argmax(reward)
+            if i == 0:
+                best_seq, best_reward = act_seqs[k], reward[k]
+            else:                                   # keep the better of the two without reading the comparison back
+                better = reward[k] > best_reward
+                best_seq, best_reward = torch.where(better, act_seqs[k], best_seq), torch.where(better, reward[k], best_reward)
+            if self.verbose:
+                model_outputs.append(model_out)
+                eval_outputs.append(eval_out)
+        best_model_out = best_eval_out = None
+        if self.rollout_best:
+            best_model_out = self.model_rollout(state_cur, best_seq[None])
+            best_eval_out = self.evaluate_traj(best_model_out["state_seqs"], best_seq[None], state_cur=state_cur)
+        return {"act_seq": best_seq, "model_outputs": model_outputs if self.verbose else None,
+                "eval_outputs": eval_outputs if self.verbose else None, "best_model_output": best_model_out,
+                "best_eval_output": best_eval_out}
+
+    def merge_res(self, res_list):
+        """Best chunk by the reward of its best sample (planner.py:312-323); ONE host read for all chunks instead of one each."""
+        assert not self.verbose and self.rollout_best
+        rewards = torch.stack([r["best_eval_output"]["reward_seqs"].mean() for r in res_list])
+        best = res_list[int(torch.argmax(rewards).item())]
+        return {"act_seq": best["act_seq"], "model_outputs": None, "eval_outputs": None,
+                "best_model_output": best["best_model_output"], "best_eval_output": best["best_eval_output"]}
+
+
 class MPPIPlanner:
     """Minimal planner with the reference Planner's MPPI branch (planner.py:38-326 keeps many unrelated modes)."""
 
     def __init__(self, model, device, ppm_optimizer, error_func, penalty_func, bbox, action_lower_lim, action_upper_lim,
-                 n_sample, n_look_ahead=1, n_update_iter=1, reward_weight=500.0, noise_level=1.0, rollout_best=True):
+                 n_sample, n_look_ahead=1, n_update_iter=1, reward_weight=500.0, noise_level=1.0, rollout_best=True, n_sample_chunk=None):
         task = ppm_optimizer.task_config
         self.device = device
         self.lo = torch.as_tensor(action_lower_lim, dtype=torch.float32, device=device)
@@ -41,6 +145,9 @@ class MPPIPlanner:
         self.n_sample, self.n_look_ahead, self.n_update_iter = n_sample, n_look_ahead, n_update_iter
         self.reward_weight, self.noise_level, self.push_length = reward_weight, noise_level, task["push_length"]
         self.rollout_best = rollout_best
+        self.model = model
+        self.n_sample_chunk = n_sample_chunk      # None: all samples in ONE rollout (the engine has no memory reason to chunk);
+                                                   # an int reproduces the reference's chunked evaluation (rope.yaml:41-42: 20 000 in chunks of 500)
         self.model_rollout = lambda state, acts: dynamics_sharded(dynamics, state, acts, model, device, ppm_optimizer)
         self.evaluate_traj = functools.partial(running_cost, error_func=error_func, penalty_func=penalty_func, bbox=bbox)
 
@@ -55,7 +162,11 @@ class MPPIPlanner:
     @torch.no_grad()
     def step(self, state_cur, act_seqs):
         """One MPPI update from GIVEN samples: rollout, rewards, softmax-weighted new sequence."""
-        out = self.model_rollout(state_cur, act_seqs)
+        if self.n_sample_chunk and self.n_sample_chunk < act_seqs.shape[0]:
+            parts = [self.model_rollout(state_cur, a) for a in act_seqs.split(self.n_sample_chunk)]
+            out = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        else:
+            out = self.model_rollout(state_cur, act_seqs)
         reward = self.evaluate_traj(out["state_seqs"], act_seqs, state_cur=state_cur)["reward_seqs"]
         new_seq = optimize_action_mppi(act_seqs, reward, reward_weight=self.reward_weight, action_lower_lim=self.lo,
                                        action_upper_lim=self.hi, push_length=self.push_length)
@@ -75,4 +186,6 @@ class MPPIPlanner:
             out = self.model_rollout(state_cur, best_seq[None])
             res["best_model_output"] = out
             res["best_eval_output"] = self.evaluate_traj(out["state_seqs"], best_seq[None], state_cur=state_cur)
+        if hasattr(self.model, "take_status"):       # the caller is about to act on the result: surface THIS call's numeric status now
+            self.model.take_status(self.device)       # (dynamics() itself only reports the previous call's, to stay sync-free)
         return res

@@ -65,13 +65,10 @@ def train(config):
                         optimizer.zero_grad(set_to_none=False)      # the gradient kernel accumulates into the kept .grad buffers
                     # parameter gradients straight into .grad for this forward + backward only (train_ops.DIRECT_GRADS is a
                     # process-wide switch: code that asks autograd for parameter gradients must find it off)
-                    train_ops.DIRECT_GRADS = ph == "train" and getattr(model, "fused_dense", False)
-                    try:
+                    with train_ops.direct_grads(ph == "train" and getattr(model, "fused_dense", False)):
                         loss = unrolled_loss(model, data, n_future)
                         if ph == "train":
                             loss.backward()
-                    finally:
-                        train_ops.DIRECT_GRADS = False
                     if ph == "train":
                         optimizer.step()
                         if i % train_config["log_interval"] == 0:

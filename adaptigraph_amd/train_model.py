@@ -4,7 +4,9 @@ src/dynamics/train/train.py:66-130).
 Same parameters, state_dict and call signature as the inference `DynamicsPredictor` (a checkpoint trained here loads into
 the fused engine unchanged), but `forward` is built from autograd-capable pieces: the three Linear(+ReLU) stacks
 (relation_encoder + the edge block of relation_propagator, particle_encoder, non_rigid_predictor: > 95 % of the dense FLOPs)
-run forward AND backward as fused exact-fp32 MFMA chain kernels (`train_ops.fused_chain`: activations stay in registers
+run forward AND backward as fused MFMA chain kernels — split-bf16 arithmetic by default (`train_ops.CHAIN_PRECISION` = 1: every
+fp32 operand as hi + lo bf16, three products, fp32 accumulate, gradients held to 1e-4 of fp64; 0 selects exact fp32 MFMA, held
+to 2e-5) — (`train_ops.fused_chain`: activations stay in registers
 between layers, weight gradients are one library GEMM per layer over the saved tables), the per-round node-level linears are
 library GEMMs (torch / hipBLASLt), and the graph part is the HIP gather / segment-reduce kernels of `train_ops` on the CSR
 adjacency — the reference's one-hot `bmm`s never exist.  The relation propagator runs in its column-split form

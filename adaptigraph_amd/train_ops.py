@@ -4,7 +4,9 @@
 their backward passes are segment sums over a (pointer, permutation) view of the same edge list, so gradients are
 reproducible bit for bit (the reference's dense bmm autograd is too; index_add-style atomics would not be).
 """
+import contextlib
 import ctypes
+import weakref
 
 import torch
 
@@ -152,13 +154,23 @@ CHAIN_PRECISION = 1     # 1: split-bf16 MFMA (x = hi + lo, three bf16 products, 
 _PACK_CACHE = {}
 
 
+def invalidate_packs():
+    """Drop every cached weight pack.  Needed only after writes the version counter cannot see: `p.data` mutation (legacy
+    optimisers, EMA swaps) or a HIP-graph replay that updated the parameters (bench_train --graph)."""
+    _PACK_CACHE.clear()
+
+
 def _pack_chain(kind, layers, dev):
     """Pack [(W, b)] into the forward stream and the transposed backward stream (device-side, one launch per layer), cached
-    until a parameter is updated in place (optimiser step) or replaced."""
+    until a parameter is updated in place (optimiser step) or replaced.  A cache entry is valid only for the SAME tensor
+    objects (weak references: a freed model's allocator blocks and version counters are routinely re-used by the next model,
+    so (data_ptr, _version) alone would hand it the old pack) at the same versions; `.data` writes bypass the version counter
+    and need invalidate_packs()."""
     prec = int(CHAIN_PRECISION)
+    base = lambda t: t._base if t._base is not None else t          # views (column slices of W_rp) share their base's version counter
     key = (kind, dev.index, prec) + tuple((W.data_ptr(), W._version, b.data_ptr(), b._version) for W, b in layers)
     hit = _PACK_CACHE.get((kind, dev.index))
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and all(r() is base(x) for r, x in zip(hit[3], (x for Wb in layers for x in Wb))):
         return hit[1], hit[2], prec
     L = _lib.lib()
     narrow = kind != "decoder"
@@ -182,7 +194,7 @@ def _pack_chain(kind, layers, dev):
             tiles = 1 if (narrow and l == 0) else 5
             _lib.check(L.ag_train_pack(W.data_ptr(), None, n_in, n_out, W.stride(0), 0, 1, 0, tiles, prec, bwd.data_ptr() + 4 * off, st), "ag_train_pack")
             off += _CHUNK * tiles
-    _PACK_CACHE[(kind, dev.index)] = (key, fwd, bwd)
+    _PACK_CACHE[(kind, dev.index)] = (key, fwd, bwd, [weakref.ref(base(x)) for Wb in layers for x in Wb])
     return fwd, bwd, prec
 
 
@@ -216,7 +228,7 @@ class _FusedChain(torch.autograd.Function):
         dev = x.device
         rows = x.shape[0]
         rows_pad = max(_ROW_TILE, -(-rows // _ROW_TILE) * _ROW_TILE)
-        fwd, bwd, prec = _pack_chain(kind, [(W.detach(), b.detach()) for W, b in layers], dev)
+        fwd, bwd, prec = _pack_chain(kind, layers, dev)             # (keyed on the parameter objects themselves, see _pack_chain)
         if kind == "decoder":
             xin = x.new_zeros((rows_pad, AG_FP))                    # saved for the backward: a fresh table per call
             xin[:rows, : x.shape[1]] = x
@@ -264,6 +276,23 @@ DIRECT_GRADS = False    # True: weight / bias gradients are ACCUMULATED straight
                         # autograd for parameter gradients (torch.autograd.grad) must leave it False.
 
 
+@contextlib.contextmanager
+def direct_grads(enabled=True):
+    """Scope DIRECT_GRADS to one forward + backward: `with train_ops.direct_grads(): loss = ...; loss.backward()`.  The flag is
+    read when a Function's forward runs and captured in its ctx, so backward passes started inside the block behave as built."""
+    global DIRECT_GRADS
+    prev, DIRECT_GRADS = DIRECT_GRADS, bool(enabled)
+    try:
+        yield
+    finally:
+        DIRECT_GRADS = prev
+
+
+def _wants_grad(t):
+    base = t._base if t._base is not None else t
+    return base.requires_grad
+
+
 def _grad_slot(t):
     """(pointer, row stride) of the .grad storage that corresponds to parameter tensor `t` — a leaf, or a column / row slice of
     one (e.g. relation_propagator.linear.weight[:, :nf]); allocates a zero .grad on first use."""
@@ -291,7 +320,12 @@ def weight_grads(dzs, prevs, n_ins, rows, params=None):
                                          i32(n_ins), rows, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, "ag_train_weight_grads")
         return out
-    slots = [(_grad_slot(W), _grad_slot(b)[0] if b is not None else None, W.shape[0]) for W, b in params]
+    keep = [l for l, (W, _) in enumerate(params) if _wants_grad(W)]          # frozen layers (requires_grad False) get no gradient
+    if len(keep) < n:
+        if keep:
+            weight_grads([dzs[l] for l in keep], [prevs[l] for l in keep], [n_ins[l] for l in keep], rows, [params[l] for l in keep])
+        return None
+    slots = [(_grad_slot(W), _grad_slot(b)[0] if (b is not None and _wants_grad(b)) else None, W.shape[0]) for W, b in params]
     pv = lambda v: (ctypes.c_void_p * 4)(*(list(v) + [None] * (4 - n)))
     with torch.cuda.device(dev):
         rc = L.ag_train_weight_grads_into(n, _ptr_array(dzs), i32(t.stride(0) for t in dzs), _ptr_array(prevs), i32(t.stride(0) for t in prevs),

@@ -95,10 +95,11 @@ def pmc_traffic(material, batch, precision, kernel):
 
 def cpu_baseline(weights, material, n_obj, kw, seconds_budget=20.0):
     """Oracle ("port" of the reference algorithm: dense-formulation forward, O(N^2) edge build, per-step rebuild)
-    on a bounded sample: as many graphs as host threads (<= 32), 2 rollout steps."""
+    on a bounded sample: ONE graph per host thread (the oracle's OpenMP loop runs over graphs, so a smaller batch would leave
+    threads idle: r02 timed 32 graphs on a 256-thread host), 2 rollout steps.  `cores` = threads that actually had a graph."""
     from oracle import ag_oracle as ago
     cores = os.cpu_count() or 1
-    bsz = max(1, min(cores, 32))
+    bsz = max(1, min(cores, 512))
     steps = 2
     state, act = synth.make_mpc_inputs(material, n_obj, bsz, seed=0, len_lo=steps, len_hi=steps + 0.9, **kw)
     task = configs.task_config(material)
@@ -111,9 +112,9 @@ def cpu_baseline(weights, material, n_obj, kw, seconds_budget=20.0):
         dt = time.perf_counter() - t0
         if dt > seconds_budget * 0.5:
             break
-    return {"value": bsz * steps * reps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{material} n_obj={n_obj}, batch {bsz}, {steps}-step rollout x {reps} reps ({dt:.1f} s), "
-                      f"OpenMP over graphs, {cores} threads"}
+    return {"value": bsz * steps * reps / dt, "unit": "graph-steps/s", "cores": min(cores, bsz), "host_threads": cores, "kind": "port",
+            "sample": f"{material} n_obj={n_obj}, batch {bsz} (one graph per host thread), {steps}-step rollout x {reps} reps ({dt:.1f} s), "
+                      f"OpenMP over graphs: {min(cores, bsz)} of {cores} host threads busy"}
 
 
 def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=12.0):
@@ -195,9 +196,12 @@ class Engine:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, batch, T, precision, streams, steps, warmup, profile=True):
+    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None):
+        """`batch` graphs per GPU (weak scaling) or, with `global_batch`, that many graphs split over the ranks (strong scaling:
+        BASELINE configs[3] = cloth batch 512 over 8 GPUs)."""
         wl = WORKLOADS[self.material]
-        B_global = batch * self.world
+        B_global = batch * self.world if global_batch is None else global_batch
+        batch = -(-B_global // self.world)
         state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
         state = torch.from_numpy(state_np).to(self.dev)           # inputs resident in HBM before the timed region
         action = torch.from_numpy(act_np).to(self.dev)
@@ -284,7 +288,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--material", default="rope", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=256, help="action samples (graphs) per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="action samples (graphs) per GPU (weak scaling: the default)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total graphs, split over the ranks (strong scaling), e.g. --material cloth --global-batch 512 --rollout-steps 20 "
+                         "= BASELINE configs[3]; overrides --batch")
+    ap.add_argument("--weights", default="seed0", help="seed0 (reference default init) or a trained set of tools/gen_trained.py, e.g. trained_rope")
     ap.add_argument("--rollout-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event roofline pass")
@@ -310,10 +318,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_seed0.npz")))
+    weights = dict(np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz")))
     eng = Engine(args.material, weights, dev, world)
     T = args.rollout_steps
-    r = eng.run(args.batch, T, args.precision, args.streams, args.steps, args.warmup, profile=not args.no_profile)
+    r = eng.run(args.batch, T, args.precision, args.streams, args.steps, args.warmup, profile=not args.no_profile,
+                global_batch=args.global_batch)
+    per_gpu = -(-r["B_global"] // world)
 
     tmax = torch.tensor([r["dt"]], dtype=torch.float64, device=dev)
     ranks = None
@@ -361,13 +371,16 @@ def main():
         line = {
             "metric": "rollout graph-steps/s (batch x rollout steps / wall; edge build + GNN forward + state update per graph-step)",
             "value": r["B_global"] * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.global_batch is None else "strong",
             "vs_baseline": None, "dtype": DTYPE_TOKEN[args.precision], "data": "synthetic",
-            "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {args.batch}/GPU, "
+            "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {per_gpu}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
-                                   f"{args.material} {wl['n_obj']} particles, batch {args.batch}/GPU, {T}-step rollout",
+                                   f"{args.material} {wl['n_obj']} particles, batch {per_gpu}/GPU"
+                                   + (f" (global batch {r['B_global']} over {world} GPUs)" if args.global_batch else "") + f", {T}-step rollout",
                        "global_batch": r["B_global"], "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather",
-                       "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)",
+                       "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)" if args.weights == "seed0" else
+                                  f"{args.weights} (the reference's train() on a toy dataset, tools/gen_trained.py)",
                        "precision": args.precision, "arithmetic": DTYPE[args.precision]},
             "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }

@@ -31,7 +31,7 @@ from adaptigraph_amd import _lib, configs, losses, mpc, synth          # noqa: E
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
 
 
-def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1):
+def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1, chunk=None, streams=None):
     """Time `steps` MPPI iterations (sample -> sharded rollout -> chamfer/penalty cost -> softmax update) on this rank's GPU.
     Returns (ms per iteration measured on this rank, last reward tensor)."""
     import time
@@ -51,12 +51,14 @@ def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup
         for p in model.parameters():
             p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
     model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[precision])
+    if streams is not None:
+        model.set_option("rollout_streams", streams)
     ppm = configs.ppm_optimizer_stub(mat)
     ppm.physics_param = {mat: torch.tensor([0.5], device=dev)}
     state_t, target_t = torch.from_numpy(state).to(dev), torch.from_numpy(target).to(dev)
     planner = mpc.MPPIPlanner(model, dev, ppm, partial(losses.chamfer, y=target_t[None]),
                               partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
-                              n_sample=samples, n_update_iter=1, rollout_best=False)
+                              n_sample=samples, n_update_iter=1, rollout_best=False, n_sample_chunk=chunk)
     act_seq = torch.from_numpy(act[0]).to(dev)
 
     def one_iteration(seq, it):
@@ -91,6 +93,9 @@ def main():
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--push-steps", type=int, default=15)
     ap.add_argument("--precision", default="fast", choices=["f32", "bf16x3", "fast"])
+    ap.add_argument("--chunk", type=int, default=None, help="evaluate the samples in chunks of this size, as the reference planner does "
+                                                          "(config/planning/rope.yaml: n_sample 20000, n_sample_chunk 500); default: one rollout")
+    ap.add_argument("--streams", type=int, default=None, help="rollout_streams engine option (default: the engine's choice)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,7 +112,7 @@ def main():
         else:
             dist.init_process_group(backend)
     _lib.lib()
-    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world)
+    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world, a.chunk, a.streams)
     tt = torch.tensor([per_it], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -121,7 +126,7 @@ def main():
             "graph_steps_per_s": round(a.samples * a.push_steps / per_it * 1e3, 1),
             "config": {"workload": f"rope-{a.particles}+1 MPPI: {a.samples} samples x {a.push_steps}-step rollout, chamfer "
                                    f"cost to a {a.particles}-point target", "samples": a.samples, "push_steps": a.push_steps,
-                       "particles": a.particles, "parallelism": f"samples/{world}"}}))
+                       "particles": a.particles, "parallelism": f"samples/{world}", "sample_chunk": a.chunk, "rollout_streams": a.streams}}))
     if world > 1:
         dist.destroy_process_group()
 

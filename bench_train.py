@@ -105,15 +105,16 @@ def main():
     model = TrainableDynamicsPredictor(configs.model_config(), configs.material_config("rope"), configs.dataset_config("rope"), dev).to(dev).train()
     model.fused_dense = not a.library_gemm
     from adaptigraph_amd import train_ops
-    train_ops.DIRECT_GRADS = model.fused_dense and not a.autograd_grads
+    direct = model.fused_dense and not a.autograd_grads     # parameter gradients straight into .grad, scoped to the training steps below
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=a.graph)
     data, csr = synthetic_batch(a.batch, a.max_nobj, dev)
     data.update(Rr=csr, Rs=None, edge_views=EdgeViews(csr))
 
     def step():
         opt.zero_grad(set_to_none=False)     # keep the .grad buffers: the gradient kernel accumulates into them
-        loss = unrolled_loss(model, data, 3)
-        loss.backward()
+        with train_ops.direct_grads(direct):
+            loss = unrolled_loss(model, data, 3)
+            loss.backward()
         opt.step()
         return loss
 
@@ -132,8 +133,9 @@ def main():
         opt.zero_grad(set_to_none=False)
         with torch.cuda.graph(g):
             opt.zero_grad(set_to_none=False)              # inside the graph: every replay starts from zero gradients
-            static_loss = unrolled_loss(model, data, 3)
-            static_loss.backward()
+            with train_ops.direct_grads(direct):
+                static_loss = unrolled_loss(model, data, 3)
+                static_loss.backward()
             opt.step()
         eager_step = step
 
@@ -142,11 +144,13 @@ def main():
             return static_loss
     ms, _ = timed(step, a.steps, a.warmup)
     line = {"metric": "training step wall-clock (3-step unroll forward + backward + Adam)", "value": round(ms, 3), "unit": "ms", "n_gpus": 1,
-            "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+            "steps": a.steps, "warmup": a.warmup, "higher_is_better": False,
+            "dtype": "f32" if (a.library_gemm or not train_ops.CHAIN_PRECISION) else "bf16x3", "data": "synthetic",
             "config": {"workload": f"rope key-point graphs, batch {a.batch}, <= {a.max_nobj}+1 nodes, {int(csr.n_rel().sum())} edges in the batch"},
             "graphs_per_s": round(a.batch / ms * 1e3, 1),
-            "dense_stacks": "library GEMMs (F.linear)" if a.library_gemm else "fused fp32-MFMA chain kernels (forward + backward)",
-            "hip_graph": bool(a.graph), "direct_grads": bool(train_ops.DIRECT_GRADS)}
+            "dense_stacks": "library GEMMs (F.linear)" if a.library_gemm else ("fused MFMA chain kernels (forward + backward), " + ("split-bf16 operands (3 bf16 products, f32 accumulate)" if train_ops.CHAIN_PRECISION else "exact f32 MFMA")),
+            "hip_graph": bool(a.graph), "direct_grads": bool(direct)}
+    train_ops.invalidate_packs()      # graph replays updated the parameters behind the version counters the pack cache keys on
     if a.dense_baseline:
         Rr, Rs = csr.to_dense(torch.float32)
         model.load_state_dict(init)

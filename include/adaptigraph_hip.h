@@ -161,7 +161,8 @@ int ag_message_backward(const float *eterm, const float *hr, const float *hs, co
                         const float *grad_agg, float *grad_edge, float *grad_hr, int64_t n_nodes, int D, ag_stream_t stream);
 
 /* ---- training path, dense stacks (row n4): the Linear(+ReLU) chains of DynamicsPredictor.forward and their backward as fused
- * exact-fp32 MFMA kernels (activations stay in registers between layers, in both directions).  Replaces the forward/backward of
+ * MFMA kernels (activations stay in registers between layers, in both directions; arithmetic per call: `precision` below — the
+ * Python training path defaults to split-bf16).  Replaces the forward/backward of
  *   AG_CHAIN_EDGE     relation_encoder.model.{0,2,4} (+ReLU each) and relation_propagator.linear[:, :nf] (no ReLU)   model.py:274,289
  *   AG_CHAIN_NODE     particle_encoder.model.{0,2,4} (+ReLU each)                                                    model.py:268
  *   AG_CHAIN_DECODER  non_rigid_predictor.linear_{0,1} (+ReLU), linear_2                                             model.py:306

@@ -171,6 +171,31 @@ def test_fused_dense_chain_forward_and_backward_vs_torch(kind, d_in, rows, preci
 
 
 @pytest.mark.gpu
+def test_pack_cache_is_keyed_on_tensor_identity_not_only_address():
+    """A model that is freed and re-created lands in the same allocator blocks with the same version counters: the
+    cached weight pack of the old model must not be served to the new one; `.data` writes need invalidate_packs()."""
+    import gc
+    torch.manual_seed(3)
+    x = torch.randn(200, 150, device=DEV)
+
+    def run(scale):
+        Ws = [(torch.randn(150, 150, device=DEV) * 0.1 * scale).requires_grad_() for _ in range(2)] + [(torch.randn(3, 150, device=DEV) * scale).requires_grad_()]
+        bs = [torch.zeros(150, device=DEV).requires_grad_() for _ in range(2)] + [torch.zeros(3, device=DEV).requires_grad_()]
+        y = train_ops.fused_chain("decoder", x, [(w, b) for w, b in zip(Ws, bs)]).detach().clone()
+        return y, [w.data_ptr() for w in Ws], Ws, bs
+
+    y1, ptr1, Ws, bs = run(1.0)
+    del Ws, bs
+    gc.collect()
+    y2, ptr2, Ws, bs = run(2.0)                      # usually the very same blocks (caching allocator), version 0 again
+    assert not torch.equal(y1, y2), f"stale pack served (same addresses: {ptr1 == ptr2})"
+    Ws[0].data.mul_(0.0)                             # invisible to the version counter
+    train_ops.invalidate_packs()
+    y3 = train_ops.fused_chain("decoder", x, [(w, b) for w, b in zip(Ws, bs)]).detach()
+    assert not torch.equal(y2, y3)
+
+
+@pytest.mark.gpu
 def test_unrolled_loss_and_gradients_match_reference(weights):
     from adaptigraph_amd.train_model import unrolled_loss
     g = load_golden("train_rope")

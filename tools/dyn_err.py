@@ -1,19 +1,19 @@
 import sys, numpy as np, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-from conftest import load_golden, golden_files
+from conftest import load_golden, golden_files, weights_for
 from adaptigraph_amd import configs
 from adaptigraph_amd.forward_dynamics import dynamics, dynamics_masked
 from adaptigraph_amd.model import DynamicsPredictor
 DEV='cuda:0'
-w=load_golden('weights_seed0')
-def mk(material, prec):
+w0=load_golden('weights_seed0')
+def mk(material, prec, w):
     m=DynamicsPredictor(configs.model_config(), configs.material_config(material), configs.dataset_config(material), DEV)
     m.load_state_dict({k: torch.from_numpy(v) for k,v in w.items()}); m=m.to(DEV).eval(); m.set_option('precision', prec); return m
 def t(x): return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 for name in golden_files('dyn_'):
     g=load_golden(name); mat=str(g['material'])
     ppm=configs.ppm_optimizer_stub(mat); ppm.physics_param={mat: torch.tensor([0.5],device=DEV)}
-    for prec in (0,1):
-        out=dynamics(t(g['state']),t(g['action']),mk(mat,prec),DEV,ppm)['state_seqs'].cpu().numpy()
+    for prec in (0,1,2):
+        out=dynamics(t(g['state']),t(g['action']),mk(mat,prec,weights_for(g,w0)),DEV,ppm)['state_seqs'].cpu().numpy()
         err=np.abs(out-g['state_seqs']); per=err.reshape(err.shape[0],-1).max(1)
         print(name, 'prec',prec,'max',err.max(),'per-sample',np.round(per,7), 'repeat', g['action'][:,:,3].astype(int).ravel())

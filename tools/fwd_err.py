@@ -4,12 +4,12 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import load_golden, golden_files
+from conftest import load_golden, golden_files, weights_for
 from adaptigraph_amd import configs
 from adaptigraph_amd.graph import CSREdges
 from adaptigraph_amd.model import DynamicsPredictor
 DEV = "cuda:0"
-w = load_golden("weights_seed0")
+w0 = load_golden("weights_seed0")
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 
 
@@ -30,7 +30,7 @@ for prec in (0, 1, 2):
         g = load_golden(name)
         mat = str(g["material"]) if "material" in g else "rope"
         m = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), DEV)
-        sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+        sd = {k: torch.from_numpy(v.copy()) for k, v in weights_for(g, w0).items()}    # seed-0 init or the trained set the golden names
         for k in sd:                                                  # the clamp golden scales the decoder (tools/gen_golden.py)
             if k.startswith("non_rigid_predictor.linear_2"): sd[k] *= float(g["decoder_scale"])
         m.load_state_dict(sd); m = m.to(DEV).eval(); m.set_option("precision", prec)
@@ -39,5 +39,6 @@ for prec in (0, 1, 2):
         scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
         e = float(np.abs(mot.cpu().numpy() - g["pred_motion"]).max())
         worst = max(worst, e / scale)
-        print(f"prec {prec} {name:22s} max-abs {e:.3e}  (|motion| max {np.abs(g['pred_motion']).max():.3f}, scaled {e / scale:.3e})")
+        st = m.take_status()
+        print(f"prec {prec} {name:34s} status {st} max-abs {e:.3e}  (|motion| max {np.abs(g['pred_motion']).max():.3f}, scaled {e / scale:.3e})")
     print(f"prec {prec} worst max-abs / max(1, |motion| max) {worst:.3e}")

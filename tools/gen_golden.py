@@ -285,6 +285,53 @@ def gen_mppi(R):
          clip_in=raw.numpy(), clip_out=R.plan_utils.clip_actions(raw, lim_lo, lim_hi).numpy(), **outs)
 
 
+# ------------------------------------------------------------------ Planner(config) (row n1: planner.py:38-326, MPPI branch)
+def toy_rollout(state_cur, act_seqs):
+    """An analytic stand-in for model_rollout_fn (the SAME function is restated in tests/test_mppi.py): every particle is
+    displaced by a smooth function of the action, accumulated over the look-ahead steps."""
+    n, L = act_seqs.shape[0], act_seqs.shape[1]
+    disp = torch.stack([torch.sin(act_seqs[..., 0]) * act_seqs[..., 3], 0.1 * act_seqs[..., 2], torch.cos(act_seqs[..., 1])], -1)  # (n, L, 3)
+    return {"state_seqs": state_cur[None, None] + 0.05 * torch.cumsum(disp, 1)[:, :, None, :] * torch.ones(n, L, state_cur.shape[0], 1)}
+
+
+def toy_cost(state_seqs, act_seqs, state_cur=None, weights=None, target=None):
+    return {"reward_seqs": -((state_seqs[:, -1] - target[None]) ** 2).sum((1, 2)) - 0.01 * (act_seqs ** 2).sum((1, 2))}
+
+
+def gen_planner(R):
+    import contextlib
+    import io
+    from functools import partial
+    rng = np.random.default_rng(77)
+    state_cur = t(rng.normal(0, 1, (12, 3)).astype(np.float32))
+    target = state_cur + t(np.array([0.3, 0.0, -0.2], np.float32))
+    lo, hi = t(np.array([-3.0, -3.0, -3.14, 1.0], np.float32)), t(np.array([3.0, 3.0, 3.14, 6.0], np.float32))
+    act0 = t(np.array([[0.5, -0.5, 0.3, 3.0], [1.0, 0.2, -0.4, 2.0]], np.float32))
+    cfg = dict(action_dim=4, model_rollout_fn=toy_rollout, evaluate_traj_fn=partial(toy_cost, target=target), n_sample=32, n_look_ahead=2,
+               n_update_iter=3, reward_weight=20.0, action_lower_lim=lo, action_upper_lim=hi, planner_type="MPPI", device="cpu",
+               noise_level=0.4)
+    out = dict(state_cur=state_cur.numpy(), target=target.numpy(), lim_lo=lo.numpy(), lim_hi=hi.numpy(), act0=act0.numpy(),
+               n_sample=np.int64(32), n_update_iter=np.int64(3), reward_weight=np.float64(20.0), noise_level=np.float64(0.4), seed=np.int64(99))
+    res_list = []
+    torch.manual_seed(99)
+    holder = []
+    # the reference calls its sampler with iter_index=... (planner.py:243), which its own default sampler does not accept: as in
+    # plan.py a sampling_action_seq_fn is always supplied — here a wrapper around that default sampler
+    cfg["sampling_action_seq_fn"] = lambda act_seq, iter_index=0: holder[-1].sample_action_sequences_default(act_seq)
+    for c in range(2):                                   # two chunks, then the reference's merge_res (plan.py chunk loop)
+        planner = R.Planner(cfg)
+        holder.append(planner)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = planner.trajectory_optimization(state_cur, act0.clone())
+        res_list.append(res)
+        out[f"chunk{c}_act_seq"] = res["act_seq"].numpy()
+        out[f"chunk{c}_best_reward"] = res["best_eval_output"]["reward_seqs"].numpy()
+        out[f"chunk{c}_best_states"] = res["best_model_output"]["state_seqs"].numpy()
+    merged = planner.merge_res(res_list)
+    out["merged_act_seq"] = merged["act_seq"].numpy()
+    save("planner_mppi_toy", **out)
+
+
 # ------------------------------------------------------------------ sys-id objective ("next" row n2, SURVEY.md §8f)
 def gen_sysid(R):
     P = R.physics_param_optimizer
@@ -520,6 +567,8 @@ def main():
     R = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "mppi":
         return gen_mppi(R)
+    if len(sys.argv) > 1 and sys.argv[1] == "planner":
+        return gen_planner(R)
     if len(sys.argv) > 1 and sys.argv[1] == "sysid":
         return gen_sysid(R)
     if len(sys.argv) > 1 and sys.argv[1] == "evalrollout":
@@ -531,6 +580,7 @@ def main():
     gen_forward(R)
     gen_rollout(R)
     gen_mppi(R)
+    gen_planner(R)
     gen_sysid(R)
     gen_evalrollout(R)
     gen_train(R)
