@@ -132,3 +132,42 @@ def test_mppi_step_vs_oracle_chain(weights):
     assert np.abs(new_seq.cpu().numpy() - upd_ref).max() <= 5e-3     # softmax(500 * reward) amplifies 1e-5 reward noise
     res = planner.trajectory_optimization_mppi(tg(state), tg(act[0]))
     assert res["act_seq"].shape == (1, 4) and torch.isfinite(res["best_reward"])
+
+
+# ------------------------------------------------------------------ Planner(config) drop-in (planner.py:38-326, MPPI branch)
+def _toy_rollout(state_cur, act_seqs):
+    """The analytic model_rollout_fn the golden was generated with (tools/gen_golden.py:toy_rollout)."""
+    n, L = act_seqs.shape[0], act_seqs.shape[1]
+    disp = torch.stack([torch.sin(act_seqs[..., 0]) * act_seqs[..., 3], 0.1 * act_seqs[..., 2], torch.cos(act_seqs[..., 1])], -1)
+    return {"state_seqs": state_cur[None, None] + 0.05 * torch.cumsum(disp, 1)[:, :, None, :] * torch.ones(n, L, state_cur.shape[0], 1)}
+
+
+def _toy_cost(state_seqs, act_seqs, state_cur=None, weights=None, target=None):
+    return {"reward_seqs": -((state_seqs[:, -1] - target[None]) ** 2).sum((1, 2)) - 0.01 * (act_seqs ** 2).sum((1, 2))}
+
+
+def test_planner_config_dropin_matches_reference_planner():
+    """`mpc.Planner(config)` with the reference's config keys, its clip / softmax update, three MPPI iterations and the two-chunk
+    merge, against the reference Planner run on the same callbacks under the same torch seed (CPU: the sampler's RNG draw order is
+    part of the contract).  As in plan.py a sampling_action_seq_fn is supplied (the reference's own default sampler does not take
+    the iter_index it is called with, planner.py:243): here a wrapper around each class's default sampler."""
+    g = load_golden("planner_mppi_toy")
+    tt = lambda k: torch.from_numpy(g[k].copy())
+    cfg = dict(action_dim=4, model_rollout_fn=_toy_rollout, evaluate_traj_fn=partial(_toy_cost, target=tt("target")), n_sample=int(g["n_sample"]),
+               n_look_ahead=2, n_update_iter=int(g["n_update_iter"]), reward_weight=float(g["reward_weight"]), action_lower_lim=tt("lim_lo"),
+               action_upper_lim=tt("lim_hi"), planner_type="MPPI", device="cpu", noise_level=float(g["noise_level"]))
+    torch.manual_seed(int(g["seed"]))
+    res, holder = [], []
+    cfg["sampling_action_seq_fn"] = lambda act_seq, iter_index=0: holder[-1].sample_action_sequences_default(act_seq)
+    for c in range(2):
+        planner = mpc.Planner(cfg)
+        holder.append(planner)
+        r = planner.trajectory_optimization(tt("state_cur"), tt("act0"))
+        assert set(r) == {"act_seq", "model_outputs", "eval_outputs", "best_model_output", "best_eval_output"}
+        assert np.abs(r["act_seq"].numpy() - g[f"chunk{c}_act_seq"]).max() <= 1e-6
+        assert np.abs(r["best_eval_output"]["reward_seqs"].numpy() - g[f"chunk{c}_best_reward"]).max() <= 1e-5
+        assert np.abs(r["best_model_output"]["state_seqs"].numpy() - g[f"chunk{c}_best_states"]).max() <= 1e-6
+        res.append(r)
+    assert np.abs(planner.merge_res(res)["act_seq"].numpy() - g["merged_act_seq"]).max() <= 1e-6
+    with pytest.raises(NotImplementedError):
+        mpc.Planner(dict(cfg, planner_type="GD")).trajectory_optimization(tt("state_cur"), tt("act0"))
