@@ -360,13 +360,18 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     ag_model *m = new ag_model();
     m->cfg = *cfg;
     if (const char *v = getenv("AG_FUSE_AGG")) m->fuse_agg = atoi(v);
+#ifndef AG_EXPERIMENTS
+    if (m->fuse_agg != 0 && m->fuse_agg != 2) m->fuse_agg = 0;
+#endif
     if (const char *v = getenv("AG_PRECISION")) {
         const int mode = (!strcmp(v, "f32") || !strcmp(v, "0")) ? 0 : (!strcmp(v, "bf16x3") || !strcmp(v, "1")) ? 1 : 2;
         m->precision = mode ? AG_PREC_B3 : AG_PREC_F32;
         m->eterm_half = mode == 2;
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
+#ifdef AG_EXPERIMENTS
     if (const char *v = getenv("AG_EDGE_ROWS")) m->edge_rows = atoi(v);
+#endif
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
@@ -596,13 +601,23 @@ int ag_set_option(ag_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
     if (!strcmp(name, "rollout_streams")) m->split = value;
-    else if (!strcmp(name, "fuse_aggregate")) m->fuse_agg = value;
+    else if (!strcmp(name, "fuse_aggregate")) {
+#ifndef AG_EXPERIMENTS
+        if (value != 0 && value != 2) return fail(AG_ERR_ARG, "ag_set_option: fuse_aggregate %d is an experiment (build with -DAG_EXPERIMENTS); the product has 0 and 2", value);
+#endif
+        m->fuse_agg = value;
+    }
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
-    else if (!strcmp(name, "edge_rows")) m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
+    else if (!strcmp(name, "edge_rows")) {
+#ifndef AG_EXPERIMENTS
+        if (value != 32) return fail(AG_ERR_ARG, "ag_set_option: edge_rows %d is an experiment (build with -DAG_EXPERIMENTS); the product runs 32 rows per wave", value);
+#endif
+        m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;
+    }   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }

@@ -346,134 +346,9 @@ struct PrecF32 {
 };
 
 
-// ---- weight pipeline of the two-block (one wave per SIMD) kernels -----------------------------------------------
-// With ONE wave per SIMD nothing else covers a stall, so the pipeline is deeper than ChunkPipe's:
-//  * FOUR 20 KB LDS buffers.  While chunk c is consumed (buffer c % 4), chunks c+1 and c+2 are resident and certified
-//    (copied, drained by every wave and barriered), and chunk c+3 is being copied into the buffer chunk c-1 left.
-//  * Copies are issued in the second half of a tile and drained in the MIDDLE of the next one, a full tile later
-//    (a drain at the tile end measured ~240 cycles per tile: a 20 KB chunk needs > 1 000 cycles to land when every CU
-//    streams); the tile-end barrier then certifies them, one tile before their first read.
-//  * The fragment-read ring wq runs ACROSS the tile barrier: the first PF k16-steps of chunk c+1 are read during the
-//    last steps of chunk c, so a tile starts with its operands in registers instead of an exposed LDS round trip.
-//    4 slots, so that the slot of a step is a compile-time function of the step count (10 steps per tile, 160 per
-//    row tile = 0 mod 4).
-struct Ring4 {
-    const float4 *g;   // weight stream (global), walked cyclically
-    int total;         // chunks in the stream
-    int fetch;         // next stream chunk to copy
-    int buf;           // ring buffer holding the chunk being consumed (0..depth-1)
-    int depth;         // 4 (one workgroup per CU) or 3 (two per CU: 60 KB each; copies issued at the START of a tile, drained at its end)
-    float *lds;        // depth * AG_CHUNK_FLOATS
-    bf16x8 wq[4][2];   // [slot][hi|lo]
-#if AG_TRACE
-    int tr = -1, trb = 0;
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_mlp_ring4.inc"
 #endif
-};
-constexpr int kRingPF = 2;
-#if AG_TRACE   // (tag, s_memtime) pairs, 256 per slot (tools/trace_e64.py)
-#define RING_STAMP(R, TAG) do { if ((R).tr >= 0 && (R).tr < 256) { ag_trace_buf[(R).trb + 2 * (R).tr] = (TAG); ag_trace_buf[(R).trb + 2 * (R).tr + 1] = __builtin_readcyclecounter(); (R).tr++; } } while (0)
-#else
-#define RING_STAMP(R, TAG) do { } while (0)
-#endif
-
-__device__ __forceinline__ unsigned ring_cur(const Ring4 &R, int lane)
-{
-    return lds_addr_of(R.lds) + (unsigned)(R.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
-}
-__device__ __forceinline__ unsigned ring_next(const Ring4 &R, int lane)
-{
-    const int nb = R.buf + 1 == R.depth ? 0 : R.buf + 1;
-    return lds_addr_of(R.lds) + (unsigned)(nb * AG_CHUNK_FLOATS * 4 + lane * 16);
-}
-// one 1 KB-per-wave piece (of five) of chunk `fetch` -> buffer (buf + depth - 1) % depth
-__device__ __forceinline__ void ring_dma_piece(Ring4 &R, int piece)
-{
-    int f = R.fetch;
-    asm volatile("" : "+s"(f));     // keep the (cyclic) chunk address out of LICM's reach, as pipe_dma does
-    const int idx = (int)(threadIdx.x + blockDim.x * piece);        // float4 index inside the chunk (1 280 per chunk)
-    if ((int)((threadIdx.x & ~63u) + blockDim.x * piece) >= AG_CHUNK_F4) return;      // wave-uniform: 512-thread workgroups need 2.5 pieces
-    const float4 *g = R.g + (size_t)f * AG_CHUNK_F4 + idx;
-    const int tb = R.buf == 0 ? R.depth - 1 : R.buf - 1;
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)R.lds;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(base + tb * AG_CHUNK_FLOATS * 4 + ((threadIdx.x & ~63u) + blockDim.x * piece) * 16);
-    dma16(g, dst);
-}
-// k16-step S (of 10) of a chunk.  depth 4: mid-tile, drain the copies issued during the previous tile, then issue this tile's
-// (chunk c+3).  depth 3: issue chunk c+2's copies over the first three steps and drain them at step 8, six steps later (with
-// two workgroups per CU a step is ~2 x 192 cycles of wall time): the tile-end barrier certifies them for the read-ahead at
-// the end of tile c+1.
-__device__ __forceinline__ void ring_feed(Ring4 &R, int S)
-{
-    if (AG_ABL & 4) return;
-    if (R.depth == 4) {
-        if (S == 5) { if (!(AG_ABL & 16)) pipe_wait(); ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
-        if (S == 6) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
-        if (S == 7) ring_dma_piece(R, 4);
-    } else {
-        if (S == 0) { ring_dma_piece(R, 0); ring_dma_piece(R, 1); }
-        if (S == 1) { ring_dma_piece(R, 2); ring_dma_piece(R, 3); }
-        if (S == 2) ring_dma_piece(R, 4);
-        if (S == 8) { if (!(AG_ABL & 16)) pipe_wait(); }
-    }
-}
-// end of a chunk: barrier (certifies the copies drained mid-tile), rotate
-__device__ __forceinline__ void ring_advance(Ring4 &R)
-{
-    R.fetch = R.fetch + 1 == R.total ? 0 : R.fetch + 1;
-    RING_STAMP(R, 4);
-    if (!(AG_ABL & 2)) __syncthreads();
-    RING_STAMP(R, 5);
-    R.buf = R.buf + 1 == R.depth ? 0 : R.buf + 1;
-}
-// k16-step S of a chunk with NS steps whose step 0 sits in ring slot PH: issue the reads of step S + PF (of the NEXT
-// chunk's first steps once S + PF >= NS: standard image offsets, valid for the compact first-layer chunk too), then
-// wait for step S's pair (exactly PF pairs were issued after it).
-template <int PH, int S, int NS>
-__device__ __forceinline__ void ring_step(Ring4 &R, unsigned la, unsigned ln)
-{
-    constexpr int T = S + kRingPF, slot = (PH + T) % 4;
-    if constexpr (T < NS) {
-        lds_read16<(2 * T) * 1024>(R.wq[slot][0], la);
-        lds_read16<(2 * T + 1) * 1024>(R.wq[slot][1], la);
-    } else {
-        lds_read16<(2 * (T - NS)) * 1024>(R.wq[slot][0], ln);
-        lds_read16<(2 * (T - NS) + 1) * 1024>(R.wq[slot][1], ln);
-    }
-    lds_wait_pair<2 * kRingPF>(R.wq[(PH + S) % 4][0], R.wq[(PH + S) % 4][1]);
-}
-// End of a chunk: the PF pairs read ahead for the next chunk must have LANDED before control leaves the straight-line
-// tile body (barrier, layer boundary, loop back-edge): an asm load's destination counts as written at the asm statement,
-// so across a join the register allocator may copy or re-assign it while the LDS return is still in flight (stale
-// fragment, or the late return lands in a register that now holds an address: observed as a memory fault).  They were
-// issued >= 2 k16-steps (12 MFMAs) earlier, so this wait does not stall.  PHN = ring slot of the next chunk's step 0.
-template <int PHN>
-__device__ __forceinline__ void ring_settle(Ring4 &R)
-{
-    static_assert(kRingPF == 2, "two pairs in flight");
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(R.wq[PHN % 4][0]), "+v"(R.wq[PHN % 4][1]), "+v"(R.wq[(PHN + 1) % 4][0]), "+v"(R.wq[(PHN + 1) % 4][1]));
-}
-// chunks 0 .. depth-2 resident and certified, chunk 0's first PF steps in registers; ring slot phase 0
-__device__ __forceinline__ void ring_start(Ring4 &R)
-{
-    const int lane = threadIdx.x & 63;
-    for (int c = 0; c < R.depth - 1; ++c) {
-        R.fetch = c < R.total ? c : 0;
-        R.buf = c + 1 == R.depth ? 0 : c + 1;                    // target (buf + depth - 1) % depth = buffer c
-#pragma unroll
-        for (int p = 0; p < 5; ++p) ring_dma_piece(R, p);
-    }
-    R.fetch = R.total > R.depth - 1 ? R.depth - 1 : 0; R.buf = 0;
-    pipe_wait();
-    __syncthreads();
-    const unsigned la = ring_cur(R, lane);
-    static_for<0, kRingPF>([&](auto U) {
-        constexpr int u = decltype(U)::value;
-        lds_read16<(2 * u) * 1024>(R.wq[u][0], la);
-        lds_read16<(2 * u + 1) * 1024>(R.wq[u][1], la);
-    });
-    ring_settle<0>(R);
-}
 
 struct PrecB3 {
     // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
@@ -613,157 +488,9 @@ struct PrecB3 {
         P.buf ^= 1;
     }
 
-    // ---- NB row blocks per wave (edge_encode_nb_kernel; NB = 2: one wave per SIMD, ~410 registers) ---------------------
-    // Every weight fragment read from LDS feeds NB B-operand blocks (NB x 32 rows), so a chunk image is copied, read
-    // and barriered once per NB x 128 rows of the workgroup: half the L2->LDS DMA bytes, ds_reads and barriers per
-    // MFMA at NB = 2.  Each block keeps its own accumulation chain in the same (lo*hi, hi*lo, hi*hi by ascending k16)
-    // order as `layer`, so a row's result does not depend on which kernel or block computed it.
-    //
-    // Epilogue scheduling.  A finished out-tile leaves 2 x NB half-tile UNITS of epilogue work (ReLU + hi/lo split or
-    // store, ~40 VALU ops each).  A lone wave must issue them in the shadow of its own MFMAs, so every tile body has
-    // four unit SLOTS, after the MFMAs of k16-steps 1, 3, 5 and 7 (3-4 VALU ops per MFMA gap, inside the ~5 a gap hides),
-    // and tile t's units run in tile t+1's slots — across layer boundaries too: `carry(b, s)` finishes the PREVIOUS
-    // layer's last tile in this layer's first tile (its s = 0 / 1 halves are k16-steps 8 / 9 of this layer's input,
-    // first needed after slot 3).  Left to the compiler, whole layers of epilogue sank into the next layer's first
-    // tile (s_memtime: 4 380 cycles for that tile instead of 2 250).  sched_barrier(0) after each slot pins the units.
-    // `prev` holds the unfinished accumulators between tiles and layers; `PH` = ring slot of the call's first k16-step.
-    template <int NB, int K, int NT, bool RELU, bool BIAS, int PH, class Epi, class Sink, class Carry>
-    __device__ __forceinline__ static void layer_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], const Epi (&epi)[NB], Sink &&sink,
-                                                    Carry &&carry)
-    {
-        static_assert(NB == 1 || NB == 2, "slot -> (block, half) mapping below");
-        constexpr int KE = K + (BIAS ? 1 : 0);
-        constexpr int NU = (KE + 15) / 16;    // k16-steps per tile
-        static_assert(NU == 10, "ring_feed / unit slots assume 10 k16-steps per chunk");
-        const int lane = threadIdx.x & 63, h = lane >> 5;
-        // bias column: activation "feature K" := 1.0 (hi) + 0.0 (lo) for the lane half that holds it, as bit masks (branch-free)
-        constexpr int o = K % 16, be = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
-        const unsigned keep = (BIAS && h == hb) ? ((be & 1) ? 0x0000ffffu : 0xffff0000u) : 0xffffffffu;
-        const unsigned one = (BIAS && h == hb) ? (0x3f80u << (16 * (be & 1))) : 0u;
-        auto unit = [&](int ti, int b, int s) {          // half s of block b of out-tile ti (accumulators in prev)
-            if (RELU) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) prev[b][8 * s + r] = (AG_ABL & 32) ? prev[b][8 * s + r] : relu1(prev[b][8 * s + r]);
-            }
-            if (!(AG_ABL & 8) || prev[b][0] == 1234.5678f) epi[b].half(ti, s, prev[b]);   // (ablation keeps the value live: no DCE)
-            sink(b, ti, s, prev[b]);
-        };
-        static_for<0, NT>([&](auto T) {
-            constexpr int ti = decltype(T)::value;
-            constexpr int ph = (PH + NU * ti) % 4;
-            const unsigned la = ring_cur(R, lane), ln = ring_next(R, lane);
-            RING_STAMP(R, 1);
-            f32x16 acc[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-            static_for<0, NU>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                ring_step<ph, u, NU>(R, la, ln);
-                const bf16x8 wh = R.wq[(ph + u) % 4][0], wl = R.wq[(ph + u) % 4][1];
-                bf16x8 xh[NB], xl[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    xh[b] = in[b].hi[u]; xl[b] = in[b].lo[u];
-                    if constexpr (BIAS && K / 16 == u) {
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        u32x4 a = __builtin_bit_cast(u32x4, xh[b]), c = __builtin_bit_cast(u32x4, xl[b]);
-                        a[be >> 1] = (a[be >> 1] & keep) | one;
-                        c[be >> 1] = c[be >> 1] & keep;
-                        xh[b] = __builtin_bit_cast(bf16x8, a); xl[b] = __builtin_bit_cast(bf16x8, c);
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[b], acc[b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[b], acc[b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[b], acc[b], 0, 0, 0);
-                ring_feed(R, u);
-                if constexpr ((u & 1) && u < 8 && (NB == 2 || (u >> 1) % 2 == 0)) {   // slot (u >> 1): units (b0,s0) (b1,s0) (b0,s1) (b1,s1); NB = 1: slots 0, 2
-                    constexpr int slot = u >> 1, ub = NB == 2 ? (slot & 1) : 0, us = slot >> 1;
-                    if constexpr (ti > 0) unit(ti - 1, ub, us); else carry(ub, us);
-#if AG_E64_PIN
-                    __builtin_amdgcn_sched_barrier(0);
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_mlp_b3_nb_layers.inc"      // layer_nb / layer_first_nb (NB row blocks per wave)
 #endif
-                }
-            });
-            RING_STAMP(R, 2);
-            ring_settle<ph + NU>(R);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) prev[b] = acc[b];
-            ring_advance(R);
-        });
-    }
-    // the units of a layer's LAST tile, for the next layer's `carry` (or run directly after the layer)
-    template <int NT, bool RELU, class Epi, class Sink>
-    __device__ __forceinline__ static void last_unit(f32x16 &pv, const Epi &epi, Sink &&sink, int b, int s)
-    {
-        if (RELU) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) pv[8 * s + r] = (AG_ABL & 32) ? pv[8 * s + r] : relu1(pv[8 * s + r]);
-        }
-        if (!(AG_ABL & 8) || pv[0] == 1234.5678f) epi.half(NT - 1, s, pv);
-        sink(b, NT - 1, s, pv);
-    }
-
-    // compact first layer (ONE chunk for all five out-tiles: [5 tiles][NU][hi|lo] = 10 consecutive k16-step images, so
-    // the fragment ring walks it like an ordinary tile); ReLU, bias column in the features.  Its 20 epilogue units
-    // outnumber its slots (60 MFMAs): out-tile t's four units run behind out-tile t+1's MFMAs, the last tile's are left
-    // in `prev` for the next layer's carry; `carry` finishes the previous ROW TILE's last layer in the first two steps.
-    template <int NB, int K, int PH, class Sink, class Carry>
-    __device__ __forceinline__ static void layer_first_nb(Ring4 &R, const Act (&in)[NB], f32x16 (&prev)[NB], Sink &&sink, Carry &&carry)
-    {
-        constexpr int NU = (K + 15) / 16, NS = AG_NT * NU;
-        static_assert(NU == 2, "compact first layer: 10 k16-step images per chunk");
-        const int lane = threadIdx.x & 63;
-        const unsigned la = ring_cur(R, lane), ln = ring_next(R, lane);
-        RING_STAMP(R, 1);
-        f32x16 cur[NB];
-        static_for<0, AG_NT>([&](auto T) {
-            constexpr int ti = decltype(T)::value;
-            f32x16 acc[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-            static_for<0, NU>([&](auto U) {
-                constexpr int u = decltype(U)::value, st = ti * NU + u;
-                ring_step<PH, st, NS>(R, la, ln);
-                const bf16x8 wh = R.wq[(PH + st) % 4][0], wl = R.wq[(PH + st) % 4][1];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, in[b].hi[u], acc[b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].lo[u], acc[b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, in[b].hi[u], acc[b], 0, 0, 0);
-                ring_feed(R, st);
-                // two units per k16-step: step u of out-tile ti finishes half s = u of both blocks of out-tile ti - 1
-                if constexpr (ti == 0) {
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) carry(b, u);
-                } else {
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) cur[b][8 * u + r] = relu1(cur[b][8 * u + r]);
-                        sink(b, ti - 1, u, cur[b]);
-                    }
-                }
-#if AG_E64_PIN
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-            });
-#pragma unroll
-            for (int b = 0; b < NB; ++b) cur[b] = acc[b];
-        });
-        RING_STAMP(R, 2);
-        ring_settle<PH + NS>(R);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) prev[b] = cur[b];
-        ring_advance(R);
-    }
 };
 
 
@@ -934,71 +661,9 @@ __device__ __forceinline__ void load_rowmajor(const float *row, f32x16 (&v)[AG_N
         }
 }
 
-// Fused segment reduction for one propagation round (model.py:283-295 after the W_rp column split):
-//     x[j] = sum_{e in CSR row g_j} relu( (Eterm[e] + Hr[g_j]) + Hs[send[e]] )       (ascending e = reference order)
-// computed by the lane pair (j, h) that owns row j's B-operand image, so the result lands directly in the
-// registers the next MFMA layer consumes (no `agg` table, no extra launch).  Memory pattern: per wave
-// instruction 32 rows x 32 contiguous bytes; each 128-B line of an Eterm row is consumed by 4 consecutive
-// instructions of the same wave (L1 hits), so HBM sees every Eterm byte once.  The loop runs to the largest
-// in-degree in the wave with the shorter rows predicated off.
-template <bool HALF>
-__device__ __forceinline__ void aggregate_rows(const AgFwdArgs &a, int g, bool valid, int h, f32x16 (&x)[AG_NT])
-{
-    int e0 = 0, deg = 0;
-    if (valid) {
-        e0 = a.row_ptr[g];
-        deg = a.row_ptr[g + 1] - e0;
-    }
-    int maxdeg = deg;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
-    f32x16 hr[AG_NT];
-    load_rowmajor(a.hr + (size_t)g * AG_FP, hr, h);
-#pragma unroll
-    for (int t = 0; t < AG_NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[t][r] = 0.0f;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    for (int d = 0; d < maxdeg; ++d) {
-        const bool act = d < deg;
-        const int e = act ? e0 + d : 0;
-        const int sidx = a.edge_send[e];
-        const float *er = a.eterm + (size_t)e * AG_FP + 4 * h;
-        const _Float16 *er16 = reinterpret_cast<const _Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h;
-        const float *sr = a.hs + (size_t)sidx * AG_FP + 4 * h;
-#pragma unroll
-        for (int t = 0; t < AG_NT; ++t) {
-            float ev[16];
-            float4 sv[4];
-            if (HALF) {
-                const h8 lo = *reinterpret_cast<const h8 *>(er16 + 32 * t), hi = *reinterpret_cast<const h8 *>(er16 + 32 * t + 8);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { ev[r] = (float)lo[r]; ev[8 + r] = (float)hi[r]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (32 * t + 8 * q < 152) {
-                    if (!HALF) {
-                        const float4 v = *reinterpret_cast<const float4 *>(er + 32 * t + 8 * q);
-                        ev[4 * q] = v.x; ev[4 * q + 1] = v.y; ev[4 * q + 2] = v.z; ev[4 * q + 3] = v.w;
-                    }
-                    sv[q] = *reinterpret_cast<const float4 *>(sr + 32 * t + 8 * q);
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (32 * t + 8 * q < 152) {
-                    const float m0 = fmaxf((ev[4 * q + 0] + hr[t][4 * q + 0]) + sv[q].x, 0.0f);
-                    const float m1 = fmaxf((ev[4 * q + 1] + hr[t][4 * q + 1]) + sv[q].y, 0.0f);
-                    const float m2 = fmaxf((ev[4 * q + 2] + hr[t][4 * q + 2]) + sv[q].z, 0.0f);
-                    const float m3 = fmaxf((ev[4 * q + 3] + hr[t][4 * q + 3]) + sv[q].w, 0.0f);
-                    x[t][4 * q + 0] += act ? m0 : 0.0f;
-                    x[t][4 * q + 1] += act ? m1 : 0.0f;
-                    x[t][4 * q + 2] += act ? m2 : 0.0f;
-                    x[t][4 * q + 3] += act ? m3 : 0.0f;
-                }
-        }
-    }
-}
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_mlp_aggregate_rows.inc"      // aggregate_rows<HALF>: fuse_aggregate 1
+#endif
 
 #define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS]; __shared__ int s_next_tile[2];
 
@@ -1177,25 +842,6 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         q.next();
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// Edge encoder, split-bf16, 64 edges per wave (two 32-row B-operand blocks share every weight fragment) — the r02
-// experiment asked for by the r01 review, kept behind ag_set_option("edge_rows", 64); NOT the default.
-// Same arithmetic as edge_encode_kernel<PrecB3>, bit for bit (tested), but ONE 256-thread workgroup per CU (one wave per
-// SIMD, ~410 registers: the activations of both blocks stay in the unified VGPR/AGPR file), so a 20 KB chunk image serves
-// 256 edges instead of 128: the L2->LDS stream drops from 2 560 to 1 280 B per edge, and so do the fragment ds_reads and
-// barriers per MFMA.  With a single wave per SIMD nothing hides a memory round trip or an epilogue, so the per-edge
-// inputs are fetched split-phase one row tile ahead, the weight ring is four deep with fragments read across the tile
-// barrier, and the epilogue runs in explicit half-tile units pinned between k16-steps (see PrecB3::layer_nb).
-// (edge_encode_nb_kernel<HALF, 2>; <HALF, 1> is the same pipeline with one row block per wave.)
-// Measured (C2, profiles/r02_edge64_*.txt): 0.847 ms per launch vs 0.843 for the 32-row kernel solo, and 99.0 k vs
-// 102.4 k graph-steps/s in the two-stream rollout (a 512-register workgroup owns its CU, so the other stream's HBM-bound
-// kernels cannot co-reside).  Why it does not win: the MFMA pipe-time floor is 1.155 M cycles per launch = 0.58-0.61 ms at
-// the 1.9-2.05 GHz the chip sustains under this load; the lone wave must also issue ~200 VALU epilogue ops + 20 ds_reads
-// + 5 DMA pieces per 60 MFMAs in its own MFMA shadow (s_memtime: 2 250-2 700 cycles per 1 920-cycle tile), and the
-// row-tile prologue (gathers, first layer: 60 MFMAs against 800 epilogue VALU ops) is exposed: 64 % pipe-busy vs 70 %
-// for two waves per SIMD — and a higher busy fraction is paid back as a lower clock (DVFS).
-// ---------------------------------------------------------------------------------------------
 
 struct EdgeRaw {           // raw gathered inputs of one edge (receiver r, sender s), model.py:220-253
     float ar[2], as[2], gr, gs;
@@ -1694,139 +1340,9 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     }
 }
 
-// NB = row blocks per wave: 2 = the 64-edges-per-wave kernel above (one workgroup per CU, 4-deep ring); 1 = the SAME pipeline with
-// 32 edges per wave, <= 256 registers and a 3-deep ring (60 KB), i.e. two workgroups per CU like edge_encode_kernel<PrecB3> but
-// with the lone-wave machinery (fragment read-ahead across the barrier, pinned epilogue units, split-phase inputs): built to
-// see whether a wave that depends less on its SIMD-mate also runs better next to one.  HALF: Eterm is the fp16 table of mode 2.
-// WAVES = 8 (with NB = 1): one 512-thread workgroup per CU whose eight waves share ONE weight ring — the L2->LDS stream of the
-// 64-row kernel (1 280 B per edge) with two waves per SIMD; all eight meet at every tile barrier (lock-step).
-template <bool HALF, int NB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (NB == 2 || WAVES == 8) ? 1 : 2) void edge_encode_nb_kernel(AgWeights w, AgFwdArgs a)
-{
-    constexpr int DEPTH = (NB == 2 || WAVES == 8) ? 4 : 3, ROWS = 32 * NB * WAVES;
-    __shared__ __attribute__((aligned(16))) float lds[DEPTH * AG_CHUNK_FLOATS];
-    __shared__ int s_next_tile[2];
-    typedef PrecB3 Prec;
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-    const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn];
-    if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
-    const int ntiles = (E + ROWS - 1) / ROWS;
-    if ((int)blockIdx.x >= ntiles) return;
-    // Row tiles are claimed from the per-launch counter TWO ahead (cur is being computed, nxt is being fetched, the
-    // claim in flight is the one after): the claimed index travels through LDS under the layers' own barriers.
-    int cur = blockIdx.x;
-    if (tid == 0) s_next_tile[0] = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
-    Ring4 P;
-    P.g = w.edge_encode_b3; P.total = 16; P.fetch = 0; P.lds = lds; P.depth = DEPTH;
-    ring_start(P);                                   // (barrier: s_next_tile[0] is visible)
-    int nxt = s_next_tile[0], par = 1;
-
-    auto edge_of = [&](int tile, int blk) { return tile * ROWS + wave * (32 * NB) + blk * 32 + j; };
-    f32x16 in0[NB];
-    {
-        EdgeRaw g[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const int e = edge_of(cur, blk);
-            const bool valid = e < E;
-            edge_gather(a, valid ? a.edge_recv[e] : 0, valid ? a.edge_send[e] : 0, g[blk]);
-        }
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) edge_features(a, g[blk], h, in0[blk]);
-    }
-    // Eterm row of (tile, block): fp16 table in precision mode 2 (320-B rows, accumulator order), fp32 otherwise
-    typedef std::conditional_t<HALF, RowStoreHalfEpi, RowStoreEpi> EtermEpi;
-    auto eterm_row = [&](int tile, int blk) {
-        const size_t e = (size_t)edge_of(tile, blk);
-        if constexpr (HALF) return EtermEpi{reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h, a.status};
-        else return EtermEpi{a.eterm + e * AG_FP + 4 * h};
-    };
-    f32x16 prev[NB];                // unfinished accumulators of the last out-tile (between tiles, layers and row tiles)
-    EtermEpi pend[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) pend[blk] = EtermEpi{nullptr};    // Eterm rows of the previous row tile's last out-tile
-    bool have_pend = false;
-    auto nosink = [](int, int, int, const f32x16 &) {};
-#if AG_TRACE
-    int it = -1;
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_mlp_edge_nb_kernel.inc"
 #endif
-#pragma unroll 1
-    while (cur < ntiles) {
-#if AG_TRACE
-        ++it;
-        {   // record the 6th row tile of wave 0 in blocks 0, 1, 128, 129
-            const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 128 ? 2 : blockIdx.x == 129 ? 3 : -1;
-            P.tr = (it == 5 && slot >= 0 && wave == 0) ? 0 : -1;
-            P.trb = (slot < 0 ? 0 : slot) * 512;
-        }
-#endif
-        RING_STAMP(P, 10);
-        int claimed = 0;
-        if (tid == 0) claimed = (int)gridDim.x + atomicAdd(a.tile_ctr, 1);
-        // phase 1 of the next row tile's inputs: edge indices (land under the first layer)
-        int nr[NB], ns[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const int e = edge_of(nxt, blk);
-            const bool valid = e < E;
-            nr[blk] = valid ? a.edge_recv[e] : 0;
-            ns[blk] = valid ? a.edge_send[e] : 0;
-        }
-        typename Prec::Act x[NB], y[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) Prec::set_tile(x[blk], 0, in0[blk]);
-        // The empty volatile asm pins a unit's result to its slot: pure VALU code has no ordering against the asm
-        // statements (fragment reads, waits, DMA) that mark the k16-steps, and instruction selection otherwise sinks it
-        // to its first use, a whole layer later.
-        auto pin = [](typename Prec::Act &t, int k) { asm volatile("" : "+v"(t.hi[k]), "+v"(t.lo[k])); };
-        auto to_y = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(y[blk], ti, s, v); pin(y[blk], 2 * ti + s); };
-        auto to_x = [&](int blk, int ti, int s, const f32x16 &v) { Prec::set_half(x[blk], ti, s, v); pin(x[blk], 2 * ti + s); };
-        const NoEpi noepi[NB] = {};
-        // fragment-ring phases: 10 k16-steps (first layer) + 3 x 50 per row tile: 0 -> 2 -> 0 -> 2 -> 0 (mod 4)
-        Prec::template layer_first_nb<NB, AG_EDGE_IN + 1, 0>(P, x, prev, to_y, [&](int b, int s) {
-            if (have_pend) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, s);     // previous row tile's Eterm, out-tile 4
-        });
-        RING_STAMP(P, 11);
-        if (tid == 0) s_next_tile[par] = claimed;
-        Prec::template layer_nb<NB, AG_F, AG_NT, true, true, 2>(P, y, prev, noepi, to_x, [&](int b, int s) {
-            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);                        // first layer, out-tile 4
-        });
-        RING_STAMP(P, 13);
-        Prec::template layer_nb<NB, AG_F, AG_NT, true, true, 0>(P, x, prev, noepi, to_y, [&](int b, int s) {
-            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_x, b, s);
-        });     // relation_encode
-        RING_STAMP(P, 14);
-        // phase 2: gather the next row tile's node rows (land under the last layer)
-        EdgeRaw g[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) edge_gather(a, nr[blk], ns[blk], g[blk]);
-        RING_STAMP(P, 15);
-        EtermEpi epi[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) epi[blk] = eterm_row(cur, blk);
-        Prec::template layer_nb<NB, AG_F, AG_NT, false, true, 2>(P, y, prev, epi, nosink, [&](int b, int s) {
-            Prec::template last_unit<AG_NT, true>(prev[b], noepi[b], to_y, b, s);
-        });
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) pend[blk] = epi[blk];
-        have_pend = true;
-        RING_STAMP(P, 16);
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) edge_features(a, g[blk], h, in0[blk]);
-        RING_STAMP(P, 17);
-        cur = nxt;
-        nxt = s_next_tile[par];
-        par ^= 1;
-        RING_STAMP(P, 18);
-    }
-    if (have_pend) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) Prec::template last_unit<AG_NT, false>(prev[b], pend[b], nosink, b, sh);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // One propagation round at node level: fused segment reduce (aggregate_rows) or a pre-computed `agg` table,
@@ -1902,8 +1418,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             }
         } else {
             f32x16 agg[AG_NT];
+#ifdef AG_EXPERIMENTS
             if (a.fuse_agg) { if (a.eterm_half) aggregate_rows<true>(a, gc, valid, h, agg); else aggregate_rows<false>(a, gc, valid, h, agg); }
-            else load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
+            else
+#endif
+            load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
 #pragma unroll
             for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
         }
@@ -2159,6 +1678,7 @@ void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
+#ifdef AG_EXPERIMENTS     // edge_rows 64 / 33 / 34: the lone-wave split-bf16 pipelines (experiments/ag_mlp_edge_nb_kernel.inc)
     if (a.precision == AG_PREC_B3 && a.edge_rows == 64 && a.tile_ctr) {     // one 512-register workgroup per CU
         const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
         const dim3 grid64(tiles < slots ? tiles : (slots > 0 ? slots : 1));
@@ -2179,6 +1699,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
         else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1, 8>), grid8, dim3(512), 0, s, w, a);
         return;
     }
+#endif
     const dim3 block(AG_MLP_THREADS);
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks

@@ -263,7 +263,7 @@ def test_forward_repeatable_with_partial_last_tile(model):
 
 @pytest.mark.parametrize("precision", ["fast", "bf16x3"])
 def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, precision):
-    """The optional split-bf16 edge encoder that gives every wave two 32-edge blocks (one 512-register workgroup per CU,
+    """(Experiment builds only: AG_LIB_PATH=ab/libexp.so from tools/ab_build.sh exp="-DAG_EXPERIMENTS".)  The optional split-bf16 edge encoder that gives every wave two 32-edge blocks (one 512-register workgroup per CU,
     ag_set_option("edge_rows", 64)) keeps each row's MFMA accumulation chain: outputs are bit-identical to the default
     32-edges-per-wave kernel, on a batch whose edge count leaves a partial 256-edge row tile, and are repeatable."""
     m = make_model(weights, prec=precision)
@@ -275,7 +275,11 @@ def test_edge_encoder_64_rows_per_wave_is_bitwise_the_32_row_kernel(weights, pre
     m.set_option("edge_products", 3)       # (mode 2's default edge stack is the two-product fp16 one; these kernels are split-bf16)
     m.set_option("edge_rows", 32)
     _, m32 = m(*args, **kw)
-    m.set_option("edge_rows", 33)          # 32 rows per wave on the lone-wave pipeline (two workgroups per CU)
+    try:
+        m.set_option("edge_rows", 33)      # 32 rows per wave on the lone-wave pipeline (two workgroups per CU)
+    except RuntimeError as e:              # the product library does not carry these kernels (csrc/experiments/, -DAG_EXPERIMENTS)
+        m.set_option("edge_products", 2)
+        pytest.skip(str(e))
     _, m33 = m(*args, **kw)
     assert torch.equal(m32, m33)
     m.set_option("edge_rows", 34)          # eight 32-row waves sharing one weight ring (one 512-thread workgroup per CU)

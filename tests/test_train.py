@@ -175,6 +175,7 @@ def test_pack_cache_is_keyed_on_tensor_identity_not_only_address():
     """A model that is freed and re-created lands in the same allocator blocks with the same version counters: the
     cached weight pack of the old model must not be served to the new one; `.data` writes need invalidate_packs()."""
     import gc
+    from adaptigraph_amd import train_ops
     torch.manual_seed(3)
     x = torch.randn(200, 150, device=DEV)
 
