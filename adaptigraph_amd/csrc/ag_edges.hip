@@ -424,18 +424,22 @@ __global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
     if (a.connect && a.variant == 1 && hit) atomicOr(&a.flag[b], 1);   // batch_mask (graph.py:123,135)
 }
 
-// The same search for large K (top-k 20, the granular configuration), where the insertion network IS the cost: ~40 in-radius
+// The same search with packed keys (the default for all three shipped top-k values; it matters most at top-k 20, the granular
+// configuration, where the insertion network IS the cost): ~40 in-radius
 // candidates per receiver x 20 compare-exchange steps x 7 VALU ops, executed by the whole wave whenever any lane accepts.
-//  * keys are ONE 32-bit word, (fp32 bits of d, sign bit dropped, low `jb` bits cleared) | j, so a compare-exchange step is
-//    v_min_u32 + v_max_u32 (2 ops instead of 7).  Truncating d is monotone, so the K smallest keys are the K nearest senders
-//    EXACTLY unless the K-th and (K+1)-th candidates agree in every kept bit of d; the network therefore carries K+1 entries
-//    and a receiver whose boundary is ambiguous is redone with the exact (d, j) network (a fraction of a percent of the
-//    receivers at N ~ 2k: d keeps 20 bits).  The in-radius test itself is made on the full fp32 d.
+//  * keys are ONE 32-bit word, (d as fixed point: floor(d * 2^(32-jb) / thr), in-radius d lies in [0, thr)) << jb | j, so a
+//    compare-exchange step is v_min_u32 + v_max_u32 (2 ops instead of 7).  The quantisation is monotone (fp32 multiply and
+//    floor are), so the K smallest keys are the K nearest senders EXACTLY unless the K-th and (K+1)-th candidates fall into the
+//    same quantum; the network therefore carries K+1 entries and a receiver whose boundary is ambiguous is redone with the
+//    exact (d, j) network.  21 bits of d at N ~ 2k: relative resolution 5e-7 of thr against ~1/40 between neighbouring order
+//    statistics, i.e. ~1e-5 of the receivers (keeping the fp32 bit pattern's leading bits instead — 12 mantissa bits — sent
+//    0.5 % of the receivers, hence every fourth WAVE, through the exact network: 0.21 ms instead of 0.12).  The in-radius test
+//    itself is made on the full fp32 d.
 //  * receivers are taken in CELL order (thread t = t-th binned particle), so the lanes of a wave walk the same cell ranges:
 //    equal trip counts and broadcast candidate loads instead of 64 unrelated walks.
 // Results are bit-identical to select_lanes_kernel / the brute-force scan (tests compare all paths with the oracle).
 template <int K>
-__global__ __launch_bounds__(256) void select_lanes_packed_kernel(AgEdgeArgs a, int jb)
+__global__ __launch_bounds__(256, 4) void select_lanes_packed_kernel(AgEdgeArgs a, int jb)
 {
     const int b = blockIdx.y, N = a.N;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -452,6 +456,9 @@ __global__ __launch_bounds__(256) void select_lanes_packed_kernel(AgEdgeArgs a, 
     const bool ti = (wi & 0x40000000) != 0;
     const float xi = me.x, yi = me.y, zi = me.z;
     const unsigned jmask = (1u << jb) - 1u;
+    const float qmax = (float)(1u << (32 - jb));                 // quanta in [0, thr): a power of two, exact in fp32
+    const float qscale = qmax / thr;
+    const unsigned qtop = (1u << (32 - jb)) - 1u;
     unsigned kl[K + 1];
 #pragma unroll
     for (int s = 0; s <= K; ++s) kl[s] = 0xffffffffu;
@@ -471,7 +478,8 @@ __global__ __launch_bounds__(256) void select_lanes_packed_kernel(AgEdgeArgs a, 
                 float d = (dx * dx + dy * dy) + dz * dz;
                 if (ti && (w & 0x40000000)) d = 1e10f;
                 if ((d - thr) < 0.0f) {
-                    unsigned key = ((__float_as_uint(d) << 1) & ~jmask) | (unsigned)(w & 0x3fffffff);
+                    const unsigned qd = min((unsigned)(d * qscale), qtop);      // monotone in d (d >= 0; a NaN never gets here)
+                    unsigned key = (qd << jb) | (unsigned)(w & 0x3fffffff);
 #pragma unroll
                     for (int s = 0; s <= K; ++s) {
                         const unsigned lo = min(kl[s], key);
@@ -682,13 +690,18 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     if (cells) {
         hipLaunchKernelGGL(bin_kernel, dim3(a.B), dim3(256), 0, s, a);
         const dim3 lgrid((a.N + 255) / 256, a.B);
-        if (a.cap0 == 5 && a.topk == 5) hipLaunchKernelGGL(select_lanes_kernel<5>, lgrid, dim3(256), 0, s, a);
-        else if (a.cap0 == 10 && a.topk == 10) hipLaunchKernelGGL(select_lanes_kernel<10>, lgrid, dim3(256), 0, s, a);
-        else if (a.cap0 == 20 && a.topk == 20) {
-            static const int packed = getenv("AG_EDGE_PACKED") ? atoi(getenv("AG_EDGE_PACKED")) : 1;      // 0: the exact (d, j) network for every receiver
-            int jb = 1;
-            while ((1 << jb) < a.N) ++jb;
-            if (packed && jb <= 16) hipLaunchKernelGGL(select_lanes_packed_kernel<20>, lgrid, dim3(256), 0, s, a, jb);
+        static const int packed = getenv("AG_EDGE_PACKED") ? atoi(getenv("AG_EDGE_PACKED")) : 1;      // 0: the exact (d, j) network for every receiver
+        int jb = 1;
+        while ((1 << jb) < a.N) ++jb;
+        const bool pk = packed && jb <= 16;          // >= 16 bits of d in the key (else nearly every boundary would be ambiguous)
+        if (a.cap0 == 5 && a.topk == 5) {
+            if (pk) hipLaunchKernelGGL(select_lanes_packed_kernel<5>, lgrid, dim3(256), 0, s, a, jb);
+            else hipLaunchKernelGGL(select_lanes_kernel<5>, lgrid, dim3(256), 0, s, a);
+        } else if (a.cap0 == 10 && a.topk == 10) {
+            if (pk) hipLaunchKernelGGL(select_lanes_packed_kernel<10>, lgrid, dim3(256), 0, s, a, jb);
+            else hipLaunchKernelGGL(select_lanes_kernel<10>, lgrid, dim3(256), 0, s, a);
+        } else if (a.cap0 == 20 && a.topk == 20) {
+            if (pk) hipLaunchKernelGGL(select_lanes_packed_kernel<20>, lgrid, dim3(256), 0, s, a, jb);
             else hipLaunchKernelGGL(select_lanes_kernel<20>, lgrid, dim3(256), 0, s, a);
         }
         else hipLaunchKernelGGL(select_cells_kernel, dim3((a.N + kRowsPerBlock - 1) / kRowsPerBlock, a.B), dim3(256), 0, s, a);

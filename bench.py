@@ -347,6 +347,17 @@ def main():
             extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"],
                                  "arithmetic": DTYPE["f32"], "roofline": e["roofline"],
                                  "note": "same workload, ag_set_option(precision, 0): the mode that matches every reference rollout golden"}
+        if args.precision == "fast":      # the middle mode: fp32-class operands everywhere (measured <= 1.2e-6 on the trained goldens, fast: <= 4.2e-5)
+            e = eng.run(args.batch, T, "bf16x3", args.streams, max(2, args.steps // 2), 1, profile=False)
+            extra["bf16x3_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "arithmetic": DTYPE["bf16x3"],
+                                    "note": "same workload, ag_set_option(precision, 1)"}
+        if args.weights == "seed0":       # throughput does not depend on the weights; the numeric status must stay clean on trained ones too
+            et = Engine(args.material, dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained_rope.npz"))), dev, world)
+            x = et.run(args.batch, T, args.precision, args.streams, max(2, args.steps // 2), 1, profile=False)
+            extra["trained_weights"] = {"value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"], "precision": args.precision,
+                                        "weights": "trained_rope (the reference's train() on a toy dataset, tools/gen_trained.py)",
+                                        "model_status": int(et.model.take_status())}
+            del et
         extra["workloads"] = {}
         for mat, b, t, tag in (("granular", 128, 10, "BASELINE configs[2]"), ("cloth", 64, 20, "BASELINE configs[3], per-GPU share of batch 512 on 8 GPUs")):
             e2 = Engine(mat, weights, dev, world)
