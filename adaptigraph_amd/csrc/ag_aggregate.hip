@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     int s[kFly];
 #pragma unroll
     for (int i = 0; i < kFly; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
-    const float4 hr = *reinterpret_cast<const float4 *>(a.hr + (size_t)g * AG_FP + 4 * c);
+    const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;
+    const float4 hr = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + 4 * c);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = e0; e < e1; e += kFly) {
         int sn[kFly];

@@ -154,6 +154,7 @@ struct ag_model {
     int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
+    int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"; 0 = every node)
     int agg_stream = 0;         // experiment builds only (-DAG_EXPERIMENTS, csrc/experiments/): 1 = LDS-DMA streamed segment reduce (measured slower)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
@@ -234,7 +235,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
 }
 
 struct FwdLayout {
-    size_t rows_pad, e_pad;
+    size_t rows_pad, e_pad, rows_c;
 };
 
 FwdLayout fwd_layout(int B, int N, int64_t e_cap)
@@ -242,22 +243,34 @@ FwdLayout fwd_layout(int B, int N, int64_t e_cap)
     FwdLayout L;
     L.rows_pad = align_up((size_t)B * N, AG_ROWS_PER_BLOCK);
     L.e_pad = align_up((size_t)(e_cap > 0 ? e_cap : 1), 256);   // whole row tiles of either edge encoder (128 / 256 edges)
+    L.rows_c = align_up((size_t)B * (N + AG_DEDUP_REPS), AG_ROWS_PER_BLOCK);      // compact rows of the de-duplicated node encoder (worst case: all private)
     return L;
 }
 
 void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
 {
     const FwdLayout L = fwd_layout(B, N, e_cap);
+    const size_t rc = L.rows_c + AG_ROWS_PER_BLOCK;              // + dump rows of the encoder's out-of-range lanes
     a.h = c.take<float>(L.rows_pad * AG_FP);
     a.pn = c.take<float>(L.rows_pad * AG_FP);
     a.hr = c.take<float>(L.rows_pad * AG_FP);
     a.hs = c.take<float>(L.rows_pad * AG_FP);
     a.hr_out = c.take<float>(L.rows_pad * AG_FP);
     a.hs_out = c.take<float>(L.rows_pad * AG_FP);
+    a.h0c = c.take<float>(rc * AG_FP);
+    a.pnc = c.take<float>(rc * AG_FP);
+    a.hrc = c.take<float>(rc * AG_FP);
+    a.hsc = c.take<float>(rc * AG_FP);
+    a.node_row = c.take<int32_t>(L.rows_pad);
+    a.enc_row = c.take<int32_t>(rc);
+    a.enc_src = c.take<int32_t>(rc);
+    a.send_c = c.take<int32_t>(L.e_pad);
+    a.rows_c = (int)L.rows_c;
     a.agg = c.take<float>(L.rows_pad * AG_FP);
     a.eterm = c.take<float>(L.e_pad * AG_FP);
     a.edge_node_tab = c.take<float>(L.rows_pad * 16);
     a.tile_ctr = c.take<int>(AG_TILE_CTRS);
+    a.enc_count = a.tile_ctr + 1;                                // (zeroed with the claim counter at the top of every forward)
 }
 
 void carve_edges(Carver &c, AgEdgeArgs &a)
@@ -299,7 +312,7 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
     ~Timed() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
+void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks)      // the model's options -> this call's kernel arguments
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
     a.precision = m->precision;
@@ -310,22 +323,47 @@ void run_encode(ag_model *m, AgFwdArgs &a, hipStream_t s, int max_blocks)
     a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
     a.edge_ws = m->edge_ws;
     a.agg_stream = m->agg_stream;
+    a.dedup = m->node_dedup && a.fuse_agg != 1 && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL;    // (the row-per-lane experiment reads Hr directly)
+    a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
         // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2: 128 -> 113.3 k, 192 -> 115.4 k, 256 -> 114.2 k)
         const int full = m->max_blocks / AG_MLP_WG_PER_CU, share = max_blocks / AG_MLP_WG_PER_CU * 3 / 2;
         a.ws_blocks = share < full ? (share > 0 ? share : 1) : (full > 0 ? full : 1);
     }
     a.status = m->status;
-    if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, AG_TILE_CTRS * sizeof(int), s);
+}
+
+// particle_encoder + hoisted Pn + the first round's Hr / Hs.  Their inputs (attrs, phys, action) do not change during a rollout
+// (forward_dynamics.py:177-180: graph["action"] is constant across the inner steps), so with node de-duplication — whose compact
+// tables no later kernel overwrites — ag_rollout runs this ONCE per call instead of once per model step.
+void run_node_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
+    if (a.dedup) (void)hipMemsetAsync(a.enc_count, 0, sizeof(int), s);
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
-    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); }
+}
+
+void run_edge_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
+    if (a.tile_ctr) (void)hipMemsetAsync(a.tile_ctr, 0, sizeof(int), s);
+    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup) ag_launch_send_remap(a, s); }
 }
 
 void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     for (int p = 0; p < a.pstep; ++p) {
-        if (!a.fuse_agg) { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(a, s); }
-        { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, a, p == a.pstep - 1, s); }
+        AgFwdArgs r = a;                 // this round's view of the tables
+        if (a.dedup) {
+            r.pn_rows = a.pnc;           // Pn: compact rows in every round
+            if (p == 0) {                // round 0 reads the encoder's compact rows: Hr through node_row, Hs through send_c, h from h0c
+                r.hr = a.hrc;
+                r.hs = a.hsc;
+                r.hr_row = a.node_row;
+                r.edge_send = a.send_c;
+                r.h_rows = a.h0c;
+            }
+        }
+        if (!r.fuse_agg) { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(r, s); }
+        { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, r, p == a.pstep - 1, s); }
         std::swap(a.hr, a.hr_out);
         std::swap(a.hs, a.hs_out);
     }
@@ -333,7 +371,9 @@ void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
 
 void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
-    run_encode(m, a, s, m->max_blocks);
+    setup_args(m, a, m->max_blocks);
+    run_node_encode(m, a, s);
+    run_edge_encode(m, a, s);
     run_propagate(m, a, s);
 }
 
@@ -376,6 +416,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
+    if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -612,6 +653,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
+    else if (!strcmp(name, "node_dedup")) m->node_dedup = value != 0;
     else if (!strcmp(name, "edge_rows")) {
 #ifndef AG_EXPERIMENTS
         if (value != 32) return fail(AG_ERR_ARG, "ag_set_option: edge_rows %d is an experiment (build with -DAG_EXPERIMENTS); the product runs 32 rows per wave", value);
@@ -864,7 +906,9 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         for (int k = 0; k < parts && rc == AG_OK; ++k) {
             hipStream_t s = run[k].s;
             { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
-            run_encode(m, part[k].f, s, part_blocks);
+            if (ai == 1) setup_args(m, part[k].f, part_blocks);
+            if (ai == 1 || !part[k].f.dedup) run_node_encode(m, part[k].f, s);       // step-invariant when de-duplicated (see run_node_encode)
+            run_edge_encode(m, part[k].f, s);
             if (ai == 1 && k == 0 && parts > 1 && m->stagger) {
                 // phase offset: the other parts start once part 0 has finished its first MFMA-bound encode stage, so
                 // from then on one stream's HBM-bound segment reduce co-runs with another stream's MFMA-bound stage

@@ -238,16 +238,20 @@ struct ZeroInit {
         return acc;
     }
 };
-struct ResidInit {  // accumulator := Pn + h (packed tables), i.e. W_pp[:, :F].enc + b_pp + residual (model.py:36-40,299-301)
-    const float *pn, *hh;   // already offset to this wave's 32-row block and this lane's (h, j)
+struct ResidInit {  // accumulator := Pn + h, i.e. W_pp[:, :F].enc + b_pp + residual (model.py:36-40,299-301).  Each source is either a
+                    // packed (fragment-image) table, pointer already offset to this wave's 32-row block and this lane's (h, j), or — node
+                    // de-duplication — a row-major row of a compact table, pointer = row + 4h
+    const float *pn, *hh;
+    bool pn_rowmajor, h_rowmajor;
     __device__ __forceinline__ f32x16 operator()(int ti) const
     {
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int off = ((ti * 4 + q) * 2) * 128;
-            const float4 a = *reinterpret_cast<const float4 *>(pn + off);
-            const float4 b = *reinterpret_cast<const float4 *>(hh + off);
+            const int off = ((ti * 4 + q) * 2) * 128, offr = 32 * ti + 8 * q;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (pn_rowmajor) { if (offr < 152) a = *reinterpret_cast<const float4 *>(pn + offr); } else a = *reinterpret_cast<const float4 *>(pn + off);
+            if (h_rowmajor) { if (offr < 152) b = *reinterpret_cast<const float4 *>(hh + offr); } else b = *reinterpret_cast<const float4 *>(hh + off);
             acc[4 * q + 0] = a.x + b.x; acc[4 * q + 1] = a.y + b.y; acc[4 * q + 2] = a.z + b.z; acc[4 * q + 3] = a.w + b.w;
         }
         return acc;
@@ -694,13 +698,99 @@ template <> __device__ __forceinline__ const float4 *pick<PrecH2>(const float4 *
 //   Hr  = W_rp[:, F:2F] . h0,  Hs = W_rp[:, 2F:3F] . h0   (receiver / sender column blocks of
 //          relation_propagator applied at NODE level instead of per edge, model.py:283-289)
 // ---------------------------------------------------------------------------------------------
-template <class Prec>
+// Node-encoder de-duplication, step 1: one WAVE per sample walks the sample's nodes in index order and maps every node to a compact
+// table row: the first AG_DEDUP_REPS distinct input rows [attrs | phys (0 for tool slots) | action] (bitwise comparison) become shared
+// rows, a node that matches none of them gets a private row.  New rows are appended to the encoder's work list (global counter: the
+// ORDER of the list does not matter, a row's MFMA chain does not depend on its position in a row tile).
+__global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
+{
+    __shared__ unsigned rep[4][AG_DEDUP_REPS][AG_NODE_IN_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= a.B) return;                                  // wave-uniform; the kernel has no workgroup-level synchronisation
+    const int N = a.N, A = AG_ATTR, Pd = a.phys_dim, D = A + Pd + 3;
+    const int base = b * (N + AG_DEDUP_REPS);
+    int nrep = 0;
+    constexpr int kPre = 8;                                // 64-node slices whose inputs are fetched together (one memory round trip per 512 nodes)
+    for (int s0 = 0; s0 < N; s0 += 64 * kPre) {
+        unsigned vv[kPre][AG_NODE_IN_MAX];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = s0 + 64 * u + lane;
+            const bool valid = i < N;
+            const size_t g = (size_t)b * N + (valid ? i : 0);
+#pragma unroll
+            for (int k = 0; k < AG_NODE_IN_MAX; ++k) {
+                float x = 0.0f;
+                if (k < A) x = a.attrs[g * A + k];
+                else if (k < A + Pd) x = (valid && i < a.n_p) ? a.phys[(size_t)b * Pd + (k - A)] : 0.0f;
+                else if (k < D) x = a.action[g * 3 + (k - A - Pd)];
+                vv[u][k] = __float_as_uint(x);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = s0 + 64 * u + lane;
+            if (s0 + 64 * u >= N) break;                       // wave-uniform
+            const bool valid = i < N;
+            const size_t g = (size_t)b * N + (valid ? i : 0);
+            unsigned (&v)[AG_NODE_IN_MAX] = vv[u];
+            int match = -1;
+            for (int r = 0; r < nrep; ++r) {
+                bool eq = true;
+#pragma unroll
+                for (int k = 0; k < AG_NODE_IN_MAX; ++k) eq = eq && v[k] == rep[wave][r][k];
+                if (eq && match < 0) match = r;
+            }
+            while (nrep < AG_DEDUP_REPS) {
+                const unsigned long long un = __ballot(valid && match < 0);
+                if (!un) break;
+                const int leader = __ffsll((long long)un) - 1;
+                bool eq = true;
+#pragma unroll
+                for (int k = 0; k < AG_NODE_IN_MAX; ++k) {
+                    const unsigned lv = (unsigned)__shfl((int)v[k], leader);
+                    if (lane == 0) rep[wave][nrep][k] = lv;
+                    eq = eq && v[k] == lv;
+                }
+                if (valid && match < 0 && eq) match = nrep;
+                if (lane == leader) {
+                    const int slot = atomicAdd(a.enc_count, 1);
+                    a.enc_row[slot] = base + nrep;
+                    a.enc_src[slot] = (int)g;
+                }
+                ++nrep;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (valid) {
+                const int row = match >= 0 ? base + match : base + AG_DEDUP_REPS + i;
+                a.node_row[g] = row;
+                if (match < 0) {
+                    const int slot = atomicAdd(a.enc_count, 1);
+                    a.enc_row[slot] = row;
+                    a.enc_src[slot] = (int)g;
+                }
+            }
+        }
+    }
+}
+
+// step 2 (independent of the encoders): the first round's sender gathers go to compact rows, so the sender column is mapped once
+__global__ __launch_bounds__(256) void send_remap_kernel(AgFwdArgs a)
+{
+    const int E = a.row_ptr[a.B * a.N];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) a.send_c[e] = a.node_row[a.edge_send[e]];
+}
+
+template <class Prec, bool DEDUP>
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-    const int Mn = a.B * a.N;
+    const int Mn = DEDUP ? *a.enc_count : a.B * a.N;      // rows to encode: the work list of node_classify_kernel, or every node
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
+    if ((int)blockIdx.x >= ntiles) return;                // (de-duplicated: a handful of row tiles)
     ChunkPipe P{pick<Prec>(w.node_encode, w.node_encode_b3), 26, 0, 0, lds};
     pipe_start(P);
     TileQueue q(nullptr, s_next_tile);   // ~4 row tiles per workgroup: nothing to balance, static stride
@@ -710,7 +800,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
         q.claim();
         const int g = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = g < Mn;
-        const int gc = valid ? g : 0;
+        const int gc = valid ? (DEDUP ? a.enc_src[g] : g) : 0;        // a node that carries this row's inputs
         const int b = gc / a.N, i = gc - b * a.N;
 
         // p_inputs = [attrs(2) | physics_param (0 for tool slots) | action(3) | 1 (bias column)], feature k = 4h + p
@@ -732,15 +822,25 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
         }
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
-        const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
-        const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         dense_first<Prec, AG_NODE_IN_MAX>(P, x, y);
         q.publish();
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
-        dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
-        dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
-        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff});  // Hr
-        dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff});  // Hs
+        if constexpr (DEDUP) {
+            // compact row-major tables at the row the work item names; lanes past the list write dump rows [rows_c, rows_c + 128)
+            const size_t row = valid ? (size_t)a.enc_row[g] : (size_t)a.rows_c + wave * 32 + j;
+            const size_t rowoff = row * AG_FP + 4 * h;
+            dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, RowStoreEpi{a.h0c + rowoff});                 // y = particle_encode = h0
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.pnc + rowoff});             // Pn
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hrc + rowoff});            // Hr (round 0 reads it through node_row)
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hsc + rowoff});            // Hs (round 0 gathers it through send_c)
+        } else {
+            const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
+            const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
+            dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{}, PackStoreEpi{a.h + blk});               // y = particle_encode = h0
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, PackStoreEpi{a.pn + blk});           // Pn
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr + rowoff});  // Hr
+            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs + rowoff});  // Hs
+        }
         q.next();
     }
 }
@@ -1428,15 +1528,18 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         }
         const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
+        // Pn (+ h in round 0) come from the compact rows of the de-duplicated node encoder when it is on
+        const size_t crow = a.pn_rows ? (size_t)a.node_row[gc] * AG_FP + 4 * h : 0;
+        const ResidInit resid{a.pn_rows ? a.pn_rows + crow : a.pn + blk, a.h_rows ? a.h_rows + crow : a.h + blk, a.pn_rows != nullptr, a.h_rows != nullptr};
         if (!LAST) {
-            dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk}, PackStoreEpi{a.h + blk});   // h'
+            dense<Prec, AG_F, true, false>(P, x, y, resid, PackStoreEpi{a.h + blk});   // h'
             q.publish();
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff});
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff});
         } else {
-            dense<Prec, AG_F, true, false>(P, x, y, ResidInit{a.pn + blk, a.h + blk});   // particle_effect'
+            dense<Prec, AG_F, true, false>(P, x, y, resid);   // particle_effect'
             q.publish();
             dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
             dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
@@ -1668,11 +1771,25 @@ static inline int grid_for(int rows, int max_blocks)
     return tiles < max_blocks ? (tiles > 0 ? tiles : 1) : max_blocks;
 }
 
+void ag_launch_send_remap(const AgFwdArgs &a, hipStream_t s)
+{
+    if (a.e_cap <= 0) return;
+    const int blocks = (a.e_cap + 255) / 256;
+    hipLaunchKernelGGL(send_remap_kernel, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, a);
+}
+
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
+    if (a.dedup) {
+        hipLaunchKernelGGL(node_classify_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
+        const dim3 gridc(grid_for(a.rows_c, a.max_blocks)), blockc(AG_MLP_THREADS);      // worst case every row is private; workgroups past the list exit
+        if (a.precision == AG_PREC_B3) hipLaunchKernelGGL((node_encode_kernel<PrecB3, true>), gridc, blockc, 0, s, w, a);
+        else hipLaunchKernelGGL((node_encode_kernel<PrecF32, true>), gridc, blockc, 0, s, w, a);
+        return;
+    }
     const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
-    if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(node_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
-    else hipLaunchKernelGGL(node_encode_kernel<PrecF32>, grid, block, 0, s, w, a);
+    if (a.precision == AG_PREC_B3) hipLaunchKernelGGL((node_encode_kernel<PrecB3, false>), grid, block, 0, s, w, a);
+    else hipLaunchKernelGGL((node_encode_kernel<PrecF32, false>), grid, block, 0, s, w, a);
 }
 
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)

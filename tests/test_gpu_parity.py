@@ -352,6 +352,48 @@ def test_fused_segment_reduce_equals_the_separate_kernel(weights):
     assert torch.equal(m(*args, **kw)[1], p1)
 
 
+@pytest.mark.parametrize("case", ["rope_gap", "distinct_actions", "granular_tools", "cloth_padded", "ten_classes"])
+def test_node_encoder_deduplication_is_bitwise_the_per_node_encoder(weights, prec, case):
+    """ag_set_option("node_dedup", 1) (default): particle_encode / Pn / the first round's Hr, Hs are computed once per distinct
+    [attrs | phys | action] row of a sample and read through an index (csrc/ag_mlp.hip node_classify_kernel).  Outputs must equal the
+    per-node encoder bit for bit — with the usual two classes (objects, tool), with a private row for EVERY node (distinct actions),
+    with several tools, padded slots, and more distinct rows than the shared slots per sample."""
+    mat = {"rope_gap": "rope", "distinct_actions": "rope", "granular_tools": "granular", "cloth_padded": "cloth", "ten_classes": "rope"}[case]
+    n_obj = {"rope_gap": 333, "distinct_actions": 150, "granular_tools": 500, "cloth_padded": 256, "ten_classes": 200}[case]
+    kw = dict(spacing=0.1) if mat == "rope" else {}
+    g = synth.make_graph_inputs(mat, n_obj, 3, seed=8, n_pad=9 if case == "cloth_padded" else 0, **kw)
+    rng = np.random.default_rng(4)
+    if case == "rope_gap":
+        g["mask"][1, 40:60] = False
+    if case == "distinct_actions":
+        g["action"] = rng.normal(0, 0.1, g["action"].shape).astype(np.float32)
+    if case == "ten_classes":
+        g["action"][:, :n_obj] = (rng.integers(0, 10, (3, n_obj, 1)) * 0.01).astype(np.float32)
+    if case == "granular_tools":
+        g["action"][:, -3:] = rng.normal(0, 0.1, (3, 3, 3)).astype(np.float32)         # tools that do not share a row
+    mm = synth.MATERIALS[mat]
+    m = make_model(weights, mat, prec=prec)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"], mm["connect_tools_all"], "batch",
+                              max_tools=g["n_tools"])
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kwp = {"action": t(g["action"]), mat + "_physics_param": t(g["phys"] * np.array([[1.0], [0.5], [0.25]], np.float32))}
+    m.set_option("node_dedup", 0)
+    pos0, mot0 = m(*args, **kwp)
+    m.set_option("node_dedup", 1)
+    for _ in range(3):
+        pos1, mot1 = m(*args, **kwp)
+        assert torch.isfinite(mot1).all() and torch.equal(mot0, mot1) and torch.equal(pos0, pos1)
+    if prec == "fast":                                            # and with the reduce fused into node_update, and through a rollout
+        m.set_option("fuse_aggregate", 2)
+        assert torch.equal(m(*args, **kwp)[1], mot0)
+        m.set_option("fuse_aggregate", 0)
+    if case == "rope_gap":
+        state, act = synth.make_mpc_inputs("rope", 300, 20, seed=4, len_lo=3, len_hi=4.9, spacing=0.1)
+        on = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+        m.set_option("node_dedup", 0)
+        assert torch.equal(on, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
+
+
 def test_forward_translation_invariance(model):
     """Positions enter only through differences (model.py:168-173 skipped, :250): shifting the cloud by a
     power-of-two offset (exact in fp32 at this magnitude) leaves pred_motion unchanged to rounding."""
