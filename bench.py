@@ -273,12 +273,15 @@ class Engine:
                 # segment reduce: Eterm streamed once (640 B/edge fp32, 320 B f16), Hs rows gathered (first touch from
                 # HBM once per node, then L2), Hr read + agg written per node (SURVEY §8d B_alg terms)
                 n_nodes = batch * (WORKLOADS[self.material]["n_obj"] + synth.MATERIALS[self.material]["n_tools"])
-                nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * 3 * 640
+                # node tables per launch: Hr read + Hs first-touch + agg write = 3 x 640 B per node; with the node encoder de-duplicated
+                # (default) round 0 reads Hr / Hs from a few compact rows, so the three rounds average (1 + 3 + 3) / 3 tables
+                tables = 3.0 if os.environ.get("AG_NODE_DEDUP", "1") == "0" else 7.0 / 3.0
+                nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * tables * 640
                 a_s = ms[ka] / cnt[ka] * 1e-3
                 t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
-                roof_hbm = {"bound": "hbm", "kernel": "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
+                roof_hbm = {"bound": "hbm", "kernel": "aggregate_half_kernel" if precision == "fast" else "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS, "traffic": t2, "traffic_source": src2,
-                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes}
+                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes, "node_tables_per_launch": tables}
         return {"roofline": roof, "roofline_hbm": roof_hbm, "kernels": kernels}
 
 
