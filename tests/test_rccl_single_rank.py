@@ -85,6 +85,23 @@ def test_bench_two_ranks_one_gpu_over_gloo():
     assert "extra" not in line and "cpu_baseline" not in line
 
 
+def test_bench_strong_scaling_global_batch_two_ranks_over_gloo():
+    """`bench.py --global-batch` (BASELINE configs[3]'s mode: a fixed global batch split over the ranks) as the driver would launch
+    it at N = 2, cloth workload, roofline objects present on the N > 1 line, scaling reported as strong."""
+    import json
+    env = dict(os.environ, AG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--material", "cloth", "--global-batch", "6", "--rollout-steps", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 6 and line["value"] > 0
+    assert "3/GPU" in line["config"]["workload"] and line["roofline"]["frac"] > 0 and line["roofline_hbm"]["frac"] > 0
+
+
 def test_mpc_bench_two_ranks_one_gpu_over_gloo():
     """bench_mpc.py (BASELINE configs[4]) with the samples sharded over two ranks: rank 0's sampled actions are broadcast, each
     rank rolls out its half, the states are all-gathered and every rank runs the cost + MPPI update on the full set.  The
