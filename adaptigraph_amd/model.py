@@ -135,7 +135,7 @@ class DynamicsPredictor(nn.Module):
         """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16 with an
         fp32 per-edge table, 2 = split-bf16 node stacks + two-product fp16 edge stack + per-edge table stored as fp16 ("fast",
         the default: all three pass the 1e-4 gate on the reference forwards; 2 can overflow for |Eterm| > 65504, see
-        take_status); "rollout_streams"; "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"; "edge_rows"."""
+        take_status); "rollout_streams"; "node_dedup"; "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"."""
         dev = torch.device(device if device is not None else self.device)
         _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
         return self

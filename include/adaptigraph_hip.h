@@ -63,18 +63,23 @@ int ag_model_destroy(ag_model *m);
  *                            models whose edge weights exceed the fp16 range keep 3), 3 = split-bf16 like precision 1
  *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
  *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
- *   "edge_rows"        32/33/34/64  split-bf16 edge encoder experiments (edge_products 3): 32 = r01 kernel; 64 = two row blocks per wave, one
- *                            workgroup per CU; 33 = 32 rows per wave on that pipeline; 34 = eight waves sharing one ring (all bit-identical)
+ *   "node_dedup"       1/0   1 (default) = particle_encoder / hoisted Pn / the first round's Hr, Hs are computed once per DISTINCT [attrs | phys | action]
+ *                            row of a sample (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout
+ *                            call; 0 = once per node and model step.  Bit-identical results
+ *   "edge_rows"        32    (33/34/64, "fuse_aggregate" 1 and "aggregate_stream" 1 select kernels that were measured slower and are compiled only into
+ *                            -DAG_EXPERIMENTS builds, csrc/experiments/; the product library refuses them)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
  *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
  *                            2 = mode 1 for the node-level stacks, the edge stack on two fp16 products per fp32 product and the per-edge
- *                            Eterm table stored as fp16 (4e-6..9.4e-6) (default 2) */
+ *                            Eterm table stored as fp16 (4e-6..9.4e-6 on default-initialised weights, 8e-6..4.2e-5 on weights trained by the
+ *                            reference's train(); precision 1 measures <= 1.2e-6 on those) (default 2) */
 int ag_set_option(ag_model *m, const char *name, int value);
 
 /* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on
  * this model produced a non-finite message sum.  With finite inputs that is an overflow of the fp16 per-edge table of
  * precision mode 2 (|Eterm| > 65504, possible with a trained checkpoint whose activations are large): switch the model
- * to precision 1.  The reference has no counterpart (it computes in fp32 throughout, model.py:283-295). */
+ * to precision 1.  (An overflow of a HIDDEN fp16 activation of that mode's edge stack can be swallowed by the next layer's ReLU and is not
+ * guaranteed to be reported: precision 1 is the setting for checkpoints with an unknown activation range.)  The reference has no counterpart (it computes in fp32 throughout, model.py:283-295). */
 enum { AG_STATUS_NONFINITE = 1 };
 int ag_model_status(ag_model *m, int *flags /*host*/, ag_stream_t stream);
 
