@@ -449,13 +449,15 @@ def _ppm(material):
     return ppm
 
 
-def explain_divergence(model, weights, material, state, action, b, state_mask=None):
+def explain_divergence(model, weights, material, state, action, b, state_mask=None, allow_drift=False):
     """Sample b of dynamics(state, action) — or, with `state_mask`, of dynamics_masked(state, state_mask, action) — left the
     1e-4 gate.  Walk the REFERENCE trajectory (oracle trace) and at every step run the engine for ONE step from the reference
     state (identical graph): its prediction must stay inside the gate, and the first step at which the engine's rebuilt edge
     list differs from the reference's must differ only by candidates whose distance gap (to the competing candidate at the
     top-k cut, or to the radius) is < 10x that step's measured position deviation.  Returns (step, deviation, gap); raises
-    AssertionError if the divergence has any other cause."""
+    AssertionError if the divergence has any other cause.  `allow_drift` (long rollouts): identical edge lists at every step with
+    every one-step deviation inside the gate is accepted too — the final difference is then the accumulated per-step rounding
+    ("gate parity per step on identical graphs; report rollout drift separately") — returns (None, max step deviation, 0)."""
     task = configs.task_config(material)
     mm = synth.MATERIALS[material]
     trace = []
@@ -468,6 +470,7 @@ def explain_divergence(model, weights, material, state, action, b, state_mask=No
     raise_by = 0.01 * task["sim_real_ratio"] if task["gripper_enable"] else 0.0
     assert len(trace) >= 2, "a one-step rollout cannot diverge through an edge flip"
     one = torch.ones(1, dtype=torch.int32, device=DEV)
+    max_dev = 0.0
     for ai in range(len(trace) - 1):
         tr, nx = trace[ai], trace[ai + 1]
         thr = aggraph.threshold_sq(tr["radius"], 1, torch.device(DEV), _lib.AG_VARIANT_BATCH)
@@ -476,6 +479,7 @@ def explain_divergence(model, weights, material, state, action, b, state_mask=No
                          raise_by, return_state=True)
         cur_e, cur_r = fin[0, -1].cpu().numpy(), nx["states"][0, -1]
         dev = float(np.abs(cur_e - cur_r).max())
+        max_dev = max(max_dev, dev)
         assert dev <= TOL_FWD, f"step {ai + 1}: one-step deviation {dev} on the identical graph"
         csr = aggraph.build_edges(fin[:, -1].contiguous(), tr["radius"], t(tr["mask"]), t(tr["tool_mask"]), mm["topk"],
                                   mm["connect_tools_all"], "batch", max_tools=mm["n_tools"])
@@ -498,6 +502,8 @@ def explain_divergence(model, weights, material, state, action, b, state_mask=No
                 worst = max(worst, abs(a - c))
         assert worst < 10 * max(dev, 1e-7), f"step {ai + 1}: edge lists differ by candidates {worst} apart, deviation {dev}"
         return ai + 1, dev, worst
+    if allow_drift:
+        return None, max_dev, 0.0
     raise AssertionError("final states differ but every rebuilt edge list equals the reference's")
 
 
@@ -536,6 +542,33 @@ def test_rollout_full_shape_vs_oracle(material, n_obj, kw, weights, prec):
     assert prec != "f32" or (err <= TOL_FWD).all(), err
     for b in np.nonzero(err > TOL_FWD)[0]:
         print(material, prec, explain_divergence(m, weights, material, state, act, int(b)))
+
+
+@pytest.mark.parametrize("material,n_obj,batch,steps", [("cloth", 4096, 64, 20), ("rope", 1000, 256, 10)])
+def test_rollout_at_the_benchmarked_config_vs_oracle(material, n_obj, batch, steps, weights, prec):
+    """BASELINE configs[3]'s per-GPU share (cloth-4k, batch 64, 20-step rollout) and configs[1] (rope-1k, batch 256, 10 steps) at FULL size:
+    four samples of the batch against the oracle's rollout of the same samples (exact-fp32 mode inside the gate outright; the split
+    modes inside it or a proven top-k near-tie), and those samples rolled out alone equal their rows of the full-batch result bit for
+    bit (batch-composition independence at the benchmarked shape, two rollout streams included)."""
+    kw = dict(spacing=0.1) if material == "rope" else {}
+    state, act = synth.make_mpc_inputs(material, n_obj, batch, seed=33, len_lo=steps, len_hi=steps + 0.9, **kw)
+    c = state.mean(0)
+    pick = [0, batch // 3, 2 * batch // 3, batch - 1]
+    for k, b in enumerate(pick):                       # pushes that start over the cloud: tool edges exist from the first step
+        act[b, 0, 0], act[b, 0, 1] = state[(k * 997) % n_obj, 0], state[(k * 997) % n_obj, 2]
+    m = make_model(weights, material, prec=prec)
+    full = dynamics(t(state), t(act), m, DEV, _ppm(material))["state_seqs"]
+    assert m.take_status() == 0
+    sub = dynamics(t(state), t(act[pick]), m, DEV, _ppm(material))["state_seqs"]
+    assert torch.equal(full[pick], sub), "a sample's rollout must not depend on the batch it is in"
+    ref, _ = ago.dynamics(weights, configs.task_config(material), state, act[pick])
+    err = np.abs(sub.cpu().numpy() - ref).reshape(len(pick), -1).max(1)
+    assert float(np.abs(ref[0, 0] - state).max()) > 1e-3, "the pushed cloud must actually move"
+    assert prec != "f32" or (err <= TOL_FWD).all(), err
+    for b in np.nonzero(err > TOL_FWD)[0]:      # 10-20 steps: per-step parity on identical graphs is the gate, the accumulated drift is reported
+        step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=True)
+        print(f"{material} {prec} sample {pick[b]}: rollout drift {err[b]:.2e} after {steps} steps; max one-step deviation on identical graphs {dev:.2e}"
+              + (f"; top-k near-tie at step {step} (candidates {gap:.2e} apart)" if step else "; edge lists equal the reference's at every step"))
 
 
 @pytest.mark.parametrize("name", golden_files("dynmask_"))
