@@ -345,9 +345,9 @@ _PENDING, _PENDING_ARMED = [], [False]
 def _flush_pending(final=True):
     by_rows = {}
     for item in _PENDING:
-        by_rows.setdefault((item[3], item[0].device), []).append(item)
+        by_rows.setdefault((item[3], item[0].device, item[5]), []).append(item)
     _PENDING.clear()
-    for (rows, _), items in by_rows.items():
+    for (rows, _, stream), items in by_rows.items():
         while items and (final or len(items) >= 8):
             # up to four layers per launch, each with its OWN destination: two layers of one launch accumulating into the same
             # parameter (the same weight in two propagation rounds) would race on its .grad
@@ -360,7 +360,9 @@ def _flush_pending(final=True):
                 else:
                     rest.append(it)
             items = rest
-            weight_grads([i[0] for i in grp], [i[1] for i in grp], [i[2] for i in grp], rows, [i[4] for i in grp])
+            with torch.cuda.stream(stream):        # the stream the backward ran on when the pair was queued (the engine's final callback may
+                                                   # run on a thread whose current stream is another one)
+                weight_grads([i[0] for i in grp], [i[1] for i in grp], [i[2] for i in grp], rows, [i[4] for i in grp])
         _PENDING.extend(items)
     if final:
         _PENDING_ARMED[0] = False
@@ -374,8 +376,9 @@ def reset_pending():
 
 def _defer_weight_grads(dz, prev, n_in, rows, params):
     """Queue layers [(dz, prev, n_in, (W, b))] sharing `rows`; call only from inside a backward pass."""
+    stream = torch.cuda.current_stream(dz[0].device)
     for z, p, k, wb in zip(dz, prev, n_in, params):
-        _PENDING.append((z, p, k, rows, wb))
+        _PENDING.append((z, p, k, rows, wb, stream))
     if not _PENDING_ARMED[0]:
         _PENDING_ARMED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
