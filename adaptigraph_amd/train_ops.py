@@ -360,8 +360,10 @@ def _flush_pending(final=True):
                 else:
                     rest.append(it)
             items = rest
-            with torch.cuda.stream(stream):        # the stream the backward ran on when the pair was queued (the engine's final callback may
-                                                   # run on a thread whose current stream is another one)
+            # on the stream the backward ran on when the pair was queued (the engine's final callback may run on a thread whose current
+            # stream is another one; switching is skipped in the common case, the step is host-bound)
+            same = stream == torch.cuda.current_stream(stream.device)
+            with (contextlib.nullcontext() if same else torch.cuda.stream(stream)):
                 weight_grads([i[0] for i in grp], [i[1] for i in grp], [i[2] for i in grp], rows, [i[4] for i in grp])
         _PENDING.extend(items)
     if final:
