@@ -154,7 +154,9 @@ struct ag_model {
     int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
                                 // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
-    int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"; 0 = every node)
+    int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
+                                // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
+                                // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
     int agg_stream = 0;         // experiment builds only (-DAG_EXPERIMENTS, csrc/experiments/): 1 = LDS-DMA streamed segment reduce (measured slower)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
@@ -312,7 +314,7 @@ struct Timed {   // RAII: bracket one kernel launch with an event pair when prof
     ~Timed() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks)      // the model's options -> this call's kernel arguments
+void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      // the model's options -> this call's kernel arguments
 {
     a.edge_counter = m->profiling ? m->edge_counter : nullptr;
     a.precision = m->precision;
@@ -323,7 +325,8 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks)      // the model's o
     a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
     a.edge_ws = m->edge_ws;
     a.agg_stream = m->agg_stream;
-    a.dedup = m->node_dedup && a.fuse_agg != 1 && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL;    // (the row-per-lane experiment reads Hr directly)
+    a.dedup = m->node_dedup && a.fuse_agg != 1 && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&    // (the row-per-lane experiment reads Hr directly)
+              (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
     a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
         // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2: 128 -> 113.3 k, 192 -> 115.4 k, 256 -> 114.2 k)
@@ -416,7 +419,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
-    if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v) != 0;
+    if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -653,7 +656,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
-    else if (!strcmp(name, "node_dedup")) m->node_dedup = value != 0;
+    else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "edge_rows")) {
 #ifndef AG_EXPERIMENTS
         if (value != 32) return fail(AG_ERR_ARG, "ag_set_option: edge_rows %d is an experiment (build with -DAG_EXPERIMENTS); the product runs 32 rows per wave", value);
@@ -906,7 +909,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         for (int k = 0; k < parts && rc == AG_OK; ++k) {
             hipStream_t s = run[k].s;
             { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
-            if (ai == 1) setup_args(m, part[k].f, part_blocks);
+            if (ai == 1) setup_args(m, part[k].f, part_blocks, p->n_steps);
             if (ai == 1 || !part[k].f.dedup) run_node_encode(m, part[k].f, s);       // step-invariant when de-duplicated (see run_node_encode)
             run_edge_encode(m, part[k].f, s);
             if (ai == 1 && k == 0 && parts > 1 && m->stagger) {

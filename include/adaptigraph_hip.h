@@ -63,9 +63,10 @@ int ag_model_destroy(ag_model *m);
  *                            models whose edge weights exceed the fp16 range keep 3), 3 = split-bf16 like precision 1
  *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
  *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
- *   "node_dedup"       1/0   1 (default) = particle_encoder / hoisted Pn / the first round's Hr, Hs are computed once per DISTINCT [attrs | phys | action]
- *                            row of a sample (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout
- *                            call; 0 = once per node and model step.  Bit-identical results
+ *   "node_dedup"       0/1/2 particle_encoder / hoisted Pn / the first round's Hr, Hs computed once per DISTINCT [attrs | phys | action] row of a sample
+ *                            (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout call: 1 (default) =
+ *                            where it pays (>= 32 768 node-rows x steps per call), 2 = always, 0 = never (once per node and model step).
+ *                            Bit-identical results
  *   "edge_rows"        32    (33/34/64, "fuse_aggregate" 1 and "aggregate_stream" 1 select kernels that were measured slower and are compiled only into
  *                            -DAG_EXPERIMENTS builds, csrc/experiments/; the product library refuses them)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
