@@ -763,11 +763,16 @@ __global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            if (valid) {
-                const int row = match >= 0 ? base + match : base + AG_DEDUP_REPS + i;
-                a.node_row[g] = row;
-                if (match < 0) {
-                    const int slot = atomicAdd(a.enc_count, 1);
+            const int row = match >= 0 ? base + match : base + AG_DEDUP_REPS + i;
+            if (valid) a.node_row[g] = row;
+            const unsigned long long priv = __ballot(valid && match < 0);       // rows of their own: one atomic per wave, not per lane
+            if (priv) {
+                const int first = __ffsll((long long)priv) - 1;
+                int slot0 = 0;
+                if (lane == first) slot0 = atomicAdd(a.enc_count, __popcll(priv));
+                slot0 = __shfl(slot0, first);
+                if (valid && match < 0) {
+                    const int slot = slot0 + __popcll(priv & ((1ull << lane) - 1ull));
                     a.enc_row[slot] = row;
                     a.enc_src[slot] = (int)g;
                 }
