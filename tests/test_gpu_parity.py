@@ -571,6 +571,34 @@ def test_rollout_at_the_benchmarked_config_vs_oracle(material, n_obj, batch, ste
               + (f"; top-k near-tie at step {step} (candidates {gap:.2e} apart)" if step else "; edge lists equal the reference's at every step"))
 
 
+def test_rollout_is_hip_graph_capturable(weights):
+    """ag_rollout never synchronises the host and joins its auxiliary streams on every path, so a caller may capture it in a HIP graph
+    (torch.cuda.graphs): the replayed rollout equals the enqueued one bit for bit, twice (replay is not faster, the point is
+    that nothing in the library prevents it)."""
+    from adaptigraph_amd.forward_dynamics import rollout as ag_roll
+    m = make_model(weights, prec="fast")
+    B, T = 24, 4
+    g = synth.make_graph_inputs("rope", 200, B, seed=3, spacing=0.1)
+    dev = torch.device(DEV)
+    thr = aggraph.threshold_sq(0.5, B, dev, _lib.AG_VARIANT_BATCH)
+    rep = torch.tensor([(b % T) + 1 for b in range(B)], dtype=torch.int32, device=dev)
+    args = (m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]), thr, rep, T, 10, False, 1)
+    ref = ag_roll(*args).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ag_roll(*args)
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out = ag_roll(*args)
+    for _ in range(2):
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("name", golden_files("dynmask_"))
 def test_dynamics_masked_golden(name, weights, prec):
     g = load_golden(name)
