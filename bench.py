@@ -67,6 +67,7 @@ DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16x2+bf16x3"}
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+MEASURED_STREAM_GBS = 5800.0      # 7:1 read:write streaming ubench on an MI355X box (profiles/r03_hbm_bw_ubench.txt), for context next to the 8 TB/s spec peak
 
 
 def csrc_sha():
@@ -281,7 +282,10 @@ class Engine:
                 t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
                 roof_hbm = {"bound": "hbm", "kernel": "aggregate_half_kernel" if precision == "fast" else "aggregate_kernel", "achieved": nbytes / a_s / 1e9, "peak": PEAK_HBM_GBS,
                             "unit": "GB/s", "frac": nbytes / a_s / 1e9 / PEAK_HBM_GBS, "traffic": t2, "traffic_source": src2,
-                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes, "node_tables_per_launch": tables}
+                            "avg_launch_ms": ms[ka] / cnt[ka], "bytes_per_launch": nbytes, "node_tables_per_launch": tables,
+                            # what a plain 7 : 1 read : write float4 streaming loop reaches on this kind of box (tools/ubench/hbm_bw.hip,
+                            # profiles/r03_hbm_bw_ubench.txt: 5.6-6.0 TB/s; read-only 5.3-5.6, copy 4.5-5.3)
+                            "stream_ceiling_measured": MEASURED_STREAM_GBS, "frac_of_stream_ceiling": nbytes / a_s / 1e9 / MEASURED_STREAM_GBS}
         return {"roofline": roof, "roofline_hbm": roof_hbm, "kernels": kernels}
 
 
