@@ -272,7 +272,7 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
     a.eterm = c.take<float>(L.e_pad * AG_FP);
     a.edge_node_tab = c.take<float>(L.rows_pad * 16);
     a.tile_ctr = c.take<int>(AG_TILE_CTRS);
-    a.enc_count = a.tile_ctr + 1;                                // (zeroed with the claim counter at the top of every forward)
+    a.enc_count = a.tile_ctr + 1;                                // (zeroed by run_node_encode before the classification fills the work list)
 }
 
 void carve_edges(Carver &c, AgEdgeArgs &a)
