@@ -394,6 +394,21 @@ def test_node_encoder_deduplication_is_bitwise_the_per_node_encoder(weights, pre
         assert torch.equal(on, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
 
 
+def test_node_deduplication_through_the_masked_rollout(weights):
+    """dynamics_masked (sys-id driver): per-sample initial clouds with padded object slots (attrs (0, 0): a second object class), the
+    node encoder hoisted out of the step loop — de-duplicated, forced and off must agree bit for bit, and with the golden."""
+    g = load_golden("dynmask_rope40")
+    m = make_model(weights, "rope", prec="fast")
+    outs = []
+    for dd in (0, 2, 1):
+        m.set_option("node_dedup", dd)
+        outs.append(dynamics_masked(t(g["state_init"]), t(g["state_mask"]), t(g["action"]), m, DEV, _ppm("rope"))["state_seqs"])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    valid = g["state_mask"]
+    err = np.abs(outs[0].cpu().numpy() - g["state_seqs"])[valid].max()
+    assert err <= 1e-3, err            # (multi-step drift of the default mode; the per-mode gate is test_dynamics_masked_golden)
+
+
 def test_forward_translation_invariance(model):
     """Positions enter only through differences (model.py:168-173 skipped, :250): shifting the cloud by a
     power-of-two offset (exact in fp32 at this magnitude) leaves pred_motion unchanged to rounding."""
