@@ -79,7 +79,9 @@ float bf16_to_f32(uint16_t b)
 // Narrow first layer (fan-in K <= 24, + bias column K): all five out-tiles in ONE chunk image.
 //   F32: [5 tiles][32 rows][32 floats], 16-byte XOR swizzle;  B3: [5 tiles][NU steps][hi|lo][64 lanes][8 bf16]
 // b3: 0 = fp32 image, 1 = split-bf16 fragment image, 2 = split-fp16 fragment image (same layout)
-void pack_first_layer(std::vector<float> &dst, int b3, const float *W, int K, int n_out, const float *bias)
+// lo_feat0 >= 0 (split-fp16 edge stack): image columns K + 1 + i repeat input column lo_feat0 + i, i < K - lo_feat0 — the kernels put the
+// fp16 rounding residual of that input there (ag_mlp.hip, f16_residual), so the first layer multiplies hi + lo of those inputs.
+void pack_first_layer(std::vector<float> &dst, int b3, const float *W, int K, int n_out, const float *bias, int lo_feat0 = -1)
 {
     const size_t base = dst.size();
     dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
@@ -90,8 +92,9 @@ void pack_first_layer(std::vector<float> &dst, int b3, const float *W, int K, in
         for (int i = 0; i < 32; ++i) {
             const int o = 32 * ti + i;
             if (o >= n_out) continue;
-            for (int k = 0; k <= K; ++k) {
-                const float v = k < K ? W[(size_t)o * K + k] : bias[o];
+            const int k_end = lo_feat0 >= 0 ? K + 1 + (K - lo_feat0) : K + 1;
+            for (int k = 0; k < k_end; ++k) {
+                const float v = k < K ? W[(size_t)o * K + k] : (k == K ? bias[o] : W[(size_t)o * K + (k - K - 1 + lo_feat0)]);
                 if (!b3) {
                     c[ti * 1024 + i * 32 + 4 * ((k >> 2) ^ ((i >> 1) & 7)) + (k & 3)] = v;
                 } else {
@@ -202,7 +205,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
         pack_layer(s, b3, t[W_D2], F, 0, F, 3, t[B_D2], 1);
     }
     const size_t off_h2 = s.size();                                        // edge_encode stream, split-fp16
-    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0]);
+    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], de - 3);      // + residual columns for the position difference, inputs 14..16 (AG_EDGE_LO_FEAT0)
     pack_layer(s, 2, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
     pack_layer(s, 2, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
     pack_layer(s, 2, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);

@@ -74,7 +74,8 @@ struct AgFwdArgs {
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
     float *edge_node_tab;  // (rows_pad, 16): per-node inputs of the edge features [attr0, attr1, group0, 0, v0(3), v1(3), v2(3), x_cur(3)] (weight-stationary edge encoder)
     int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
-    int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced (ag_model_status)
+    int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced, bit 1 = a precision-mode-2 forward
+                       // predicted a motion component beyond AG_FAST_ENVELOPE (ag_model_status)
     int edge_products; // precision mode 2 only: 2 = fp16 activations x split-fp16 weights in the edge stack (default), 3 = split-bf16 like mode 1
     int ws_blocks;     // workgroups of the weight-stationary edge encoder for this launch
     int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
@@ -99,6 +100,11 @@ struct AgFwdArgs {
                        // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };
 #define AG_TILE_CTRS 4
+// Precision mode 2 ("fast") deviates from the fp32 forward by about 5e-4 of the largest predicted motion (fp16 activations in the edge stack and the
+// fp16 per-edge table; tools/fuzz_parity.py: <= 7.6e-4 x max|motion| over 1 100 random graphs, worst on weights trained by the reference's train()),
+// i.e. it stays inside the 1e-4 gate while per-step motions stay below ~0.13.  A mode-2 forward that predicts a larger component raises status
+// bit 1 (AG_STATUS_FAST_ENVELOPE) instead of passing a possibly-outside-the-gate result on silently.
+#define AG_FAST_ENVELOPE 0.125f
 #define AG_DEDUP_REPS 8            // distinct node-encoder input rows shared within a sample (more than that: private rows)
 
 // ---- segment reduce of ONE node with the fp16 per-edge table (precision mode 2), shared by aggregate_half_kernel

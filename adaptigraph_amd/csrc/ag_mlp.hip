@@ -517,6 +517,17 @@ struct PrecB3 {
 // Eterm overflow, not a guarantee for the hidden activations: for checkpoints with an unknown activation range use precision 1
 // (split-bf16, fp32 range).  Measured head-room: the trained goldens rescaled to 64x larger edge-stack activations
 // (tests/golden/*act64*, tools/gen_trained.py) still match within the mode's tolerance with status 0.
+// FIRST layer of the edge stack: its 17 inputs + bias column use 18 of the 32 K slots of two k16-steps.  Three of the inputs are the current
+// position difference x_r - x_s, of any size (a tool joined to every cloth particle by connect_tools_all sits metres away: |x| ~ 50 rounds to
+// fp16 with an error of 0.01; the velocity differences are 10-100x smaller and so are their rounding errors).  Spare slots 18..20 carry the
+// fp16 rounding residuals of inputs 14..16 against the same weight columns (ag_api.hip pack_first_layer), so the first layer sees those
+// inputs to 2^-22 at no extra MFMA: tools/fuzz_parity.py's worst mode-2 cases were these.
+#define AG_EDGE_LO_SLOT0 (AG_EDGE_IN + 1)       // first residual slot
+#define AG_EDGE_LO_FEAT0 (AG_EDGE_IN - 3)       // first input with a residual: cur_r - cur_s (model.py:249-250)
+#define AG_EDGE_LO_COUNT 3
+static_assert(AG_EDGE_LO_SLOT0 == 18 && AG_EDGE_LO_FEAT0 == 14, "edge_encode_ws_kernel builds slots 18..20 by hand");
+__device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
+
 struct PrecH2 {
     struct Act { f16x8 v[2 * AG_NT]; };
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
@@ -933,6 +944,19 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
+        if constexpr (std::is_same<Prec, PrecH2>::value) {      // fp16 residuals of the position inputs in the spare K slots (see f16_residual)
+#pragma unroll
+            for (int q = 2; q < 4; ++q)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int k0 = 8 * q + p, k1 = k0 + 4;      // this lane half's slot: k0 (h = 0) or k1 (h = 1)
+                    const bool l0 = k0 >= AG_EDGE_LO_SLOT0 && k0 < AG_EDGE_LO_SLOT0 + AG_EDGE_LO_COUNT;
+                    const bool l1 = k1 >= AG_EDGE_LO_SLOT0 && k1 < AG_EDGE_LO_SLOT0 + AG_EDGE_LO_COUNT;
+                    const float v0 = l0 ? f16_residual(feat[k0 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k0 < 24 ? feat[k0] : 0.0f);
+                    const float v1 = l1 ? f16_residual(feat[k1 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k1 < 24 ? feat[k1] : 0.0f);
+                    in0[4 * q + p] = h ? v1 : v0;
+                }
+        }
 
         typename Prec::Act x, y;
         Prec::set_tile(x, 0, in0);
@@ -1322,6 +1346,9 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         float feat[24];
 #pragma unroll
         for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        ws_u32x4 X1 = {0u, 0u, 0u, 0u};      // k16-step 1 of the block's first-layer input image
         const float4 *tab = reinterpret_cast<const float4 *>(a.edge_node_tab);
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
@@ -1342,20 +1369,27 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
                     feat[9] = R[2].x - S[2].x; feat[10] = R[2].y - S[2].y; feat[11] = R[2].z - S[2].z; feat[12] = R[2].w - S[2].w;
                     feat[13] = R[3].x - S[3].x; feat[14] = R[3].y - S[3].y; feat[15] = R[3].z - S[3].z; feat[16] = R[3].w - S[3].w;
                 }
-                // lane half h keeps features 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (16..23, rest zero)
-                if constexpr (p == 16 || p == 17) {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-                    constexpr int s16 = p - 16;
-                    ws_u32x4 X = {0u, 0u, 0u, 0u};
+                // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (16, the bias 1.0, then the fp16
+                // residuals of features 14..16 in slots 18..20: f16_residual; the same values in the same slots as edge_encode_kernel<PrecH2>)
+                if constexpr (p == 16) {
+                    ws_u32x4 X;
 #pragma unroll
-                    for (int q = 2 * s16; q < 2 * s16 + 2 && q < 3; ++q)
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const f32x2 v = {h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]};
-                            X[2 * (q - 2 * s16) + c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+                            X[2 * q + c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
                         }
-                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024 * s16]) = X;
+                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16]) = X;
+                }
+                if constexpr (p == 17) {        // slots 16, 17 (h = 0) | 20, 21 (h = 1) and 18, 19 | 22, 23; slots 24..31 stay zero
+                    const float r16 = f16_residual(feat[16]);
+                    const f32x2 v0 = {h ? r16 : feat[16], h ? 0.0f : feat[AG_EDGE_IN]};
+                    const f32x2 s1 = {h ? 0.0f : feat[14], h ? 0.0f : feat[15]};
+                    const f32x2 v1 = {f16_residual(s1[0]), f16_residual(s1[1])};
+                    X1[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, f16x2));
+                    X1[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, f16x2));
+                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024]) = X1;
                 }
             });
             WS_STAMP(2);
@@ -1562,6 +1596,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                     pm[c] = mv;
                     pp[c] = cur[c] + fminf(fmaxf(mv, -a.clamp), a.clamp);   // model.py:309
                 }
+            }
+            // precision mode 2 outside the motion range its 1e-4 deviation was validated on (ag_common.h): say so instead of passing it on
+            if (a.eterm_half && a.status) {
+                const bool big = valid && h == 0 && i < a.n_p && fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fabsf(m[2])) > AG_FAST_ENVELOPE;
+                if (__any(big) && (threadIdx.x & 63) == 0) atomicOr(a.status, 2);     // AG_STATUS_FAST_ENVELOPE, one atomic per wave
             }
         }
         q.next();

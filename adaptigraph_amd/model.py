@@ -120,7 +120,8 @@ class DynamicsPredictor(nn.Module):
     def take_status(self, device=None):
         """Read-and-clear the model's sticky numeric status (ag_model_status; synchronises the current stream).
         Bit 0: a non-finite message sum was produced — with finite inputs, an fp16 overflow of the per-edge table in
-        precision mode 2; warns once per occurrence and returns the flag word."""
+        precision mode 2.  Bit 1: a mode-2 forward predicted a motion component above 0.125, the range that mode's 1e-4
+        deviation is validated on (include/adaptigraph_hip.h).  Warns once per occurrence and returns the flag word."""
         dev = torch.device(device if device is not None else self.device)
         flags = ctypes.c_int(0)
         with torch.cuda.device(dev):
@@ -129,6 +130,10 @@ class DynamicsPredictor(nn.Module):
             warnings.warn("adaptigraph_amd: a forward produced non-finite message sums. If the inputs were finite, the fp16 "
                           "per-edge table of precision mode 2 ('fast') overflowed (|Eterm| > 65504): use "
                           "model.set_option('precision', 1).", RuntimeWarning, stacklevel=2)
+        if flags.value & 2:
+            warnings.warn("adaptigraph_amd: a forward in precision mode 2 ('fast') predicted a per-step motion above 0.125. That mode "
+                          "deviates from the fp32 forward by about 5e-4 of the largest motion, so the 1e-4 max-abs gate is not guaranteed "
+                          "at this motion size: model.set_option('precision', 1) holds it (<= 6e-6) at any size.", RuntimeWarning, stacklevel=2)
         return flags.value
 
     def set_option(self, name, value, device=None):

@@ -80,8 +80,12 @@ int ag_set_option(ag_model *m, const char *name, int value);
  * this model produced a non-finite message sum.  With finite inputs that is an overflow of the fp16 per-edge table of
  * precision mode 2 (|Eterm| > 65504, possible with a trained checkpoint whose activations are large): switch the model
  * to precision 1.  (An overflow of a HIDDEN fp16 activation of that mode's edge stack can be swallowed by the next layer's ReLU and is not
- * guaranteed to be reported: precision 1 is the setting for checkpoints with an unknown activation range.)  The reference has no counterpart (it computes in fp32 throughout, model.py:283-295). */
-enum { AG_STATUS_NONFINITE = 1 };
+ * guaranteed to be reported: precision 1 is the setting for checkpoints with an unknown activation range.)
+ * Bit 1 (AG_STATUS_FAST_ENVELOPE) = a precision-mode-2 forward predicted a motion component larger than 0.125.  Mode 2 deviates from the fp32
+ * forward by about 5e-4 of the largest predicted motion (measured <= 7.6e-4 x max|motion| on weights trained by the reference's train(),
+ * tools/fuzz_parity.py), so beyond that size the 1e-4 max-abs gate is no longer guaranteed: precision 1 holds it at any motion size (<= 6e-6).
+ * The reference has no counterpart to either bit (it computes in fp32 throughout, model.py:283-295). */
+enum { AG_STATUS_NONFINITE = 1, AG_STATUS_FAST_ENVELOPE = 2 };
 int ag_model_status(ag_model *m, int *flags /*host*/, ag_stream_t stream);
 
 /* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */
