@@ -354,7 +354,7 @@ def main():
             extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"],
                                  "arithmetic": DTYPE["f32"], "roofline": e["roofline"],
                                  "note": "same workload, ag_set_option(precision, 0): the mode that matches every reference rollout golden"}
-        if args.precision == "fast":      # the middle mode: fp32-class operands everywhere (measured <= 1.2e-6 on the trained goldens, fast: <= 4.2e-5)
+        if args.precision == "fast":      # the middle mode: fp32-class operands everywhere (measured <= 1.2e-6 on the trained goldens, fast: <= 4.7e-5)
             e = eng.run(args.batch, T, "bf16x3", args.streams, max(2, args.steps // 2), 1, profile=False)
             extra["bf16x3_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "arithmetic": DTYPE["bf16x3"],
                                     "note": "same workload, ag_set_option(precision, 1)"}

@@ -72,7 +72,7 @@ int ag_model_destroy(ag_model *m);
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
  *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
  *                            2 = mode 1 for the node-level stacks, the edge stack on two fp16 products per fp32 product and the per-edge
- *                            Eterm table stored as fp16 (4e-6..9.4e-6 on default-initialised weights, 8e-6..4.2e-5 on weights trained by the
+ *                            Eterm table stored as fp16 (4e-6..9.4e-6 on default-initialised weights, 8e-6..4.7e-5 on weights trained by the
  *                            reference's train(); precision 1 measures <= 1.2e-6 on those) (default 2) */
 int ag_set_option(ag_model *m, const char *name, int value);
 

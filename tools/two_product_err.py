@@ -15,7 +15,7 @@ h16 = lambda x: x.half().double()
 b16 = lambda x: x.bfloat16().double()
 
 
-def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None, etq=None):
+def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None, etq=None, res_cols=0):
     use_weights(g)
     # groups: node-level layer groups whose INPUTS are rounded with xq: 'pe' particle_encoder, 'pp' particle_propagator (both
     # column blocks), 'rs' W_r / W_s (relation_propagator node blocks), 'dec' non_rigid_predictor
@@ -37,7 +37,12 @@ def forward(g, wq, xq, first, node=False, hsq=None, hrq=None, groups=None, etq=N
         for i in (0, 2, 4): x = F.relu(lin(x, W[f"particle_encoder.model.{i}.weight"], W[f"particle_encoder.model.{i}.bias"], G('pe')))
         enc_n = x
         x = rel
-        for i in (0, 2, 4): x = F.relu(lin(x, W[f"relation_encoder.model.{i}.weight"], W[f"relation_encoder.model.{i}.bias"], first or i > 0))
+        if res_cols and first:      # r03: the last inputs (x_r - x_s) carry their fp16 residual in spare K slots of layer 1 (ag_mlp.hip f16_residual)
+            xe = xq(x); xe[:, -res_cols:] = xe[:, -res_cols:] + xq(x[:, -res_cols:] - xe[:, -res_cols:])
+            x = F.relu(F.linear(xe, wq(W["relation_encoder.model.0.weight"]), W["relation_encoder.model.0.bias"]))
+        else:
+            x = F.relu(lin(x, W["relation_encoder.model.0.weight"], W["relation_encoder.model.0.bias"], first))
+        for i in (2, 4): x = F.relu(lin(x, W[f"relation_encoder.model.{i}.weight"], W[f"relation_encoder.model.{i}.bias"], True))
         wrp, brp = W["relation_propagator.linear.weight"], W["relation_propagator.linear.bias"]
         wpp, bpp = W["particle_propagator.linear.weight"], W["particle_propagator.linear.bias"]
         eterm = lin(x, wrp[:, :150], brp, True)
@@ -89,10 +94,11 @@ for label, wq, xq, first, node in cases:
         errs.append(f"{name[4:]} {np.abs(forward(g, wq, xq, first, node) - g['pred_motion']).max():.2e}")
     print(f"{label:40s}", " | ".join(errs))
 # the shipped mode 2 and the one-product candidate, both WITH the fp16 per-edge table (what the engine would actually compute)
-for label, wq, xq in (("mode 2 as shipped: B 1-4 + Eterm fp16", ident, h16), ("ONE product: C 1-4 + Eterm fp16", h16, h16)):
+for label, wq, xq, res in (("mode 2 until r03: B 1-4 + Eterm fp16", ident, h16, 0), ("mode 2 as shipped: + residuals of x_r - x_s", ident, h16, 3),
+                           ("ONE product: C 1-4 + Eterm fp16", h16, h16, 0)):
     errs = []
     for name in golden_files("fwd_"):
         g = load_golden(name)
         if float(g["decoder_scale"]) != 1.0: continue
-        errs.append(f"{name[4:]} {np.abs(forward(g, wq, xq, True, False, etq=h16) - g['pred_motion']).max():.2e}")
+        errs.append(f"{name[4:]} {np.abs(forward(g, wq, xq, True, False, etq=h16, res_cols=res) - g['pred_motion']).max():.2e}")
     print(f"{label:40s}", " | ".join(errs))
