@@ -129,7 +129,11 @@ void pack_layer(std::vector<float> &dst, int b3, const float *W, int ld, int col
                 } else {
                     const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
                     uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
-                    if (b3 == 2) f16_split(v, hi, lo);
+                    if (b3 >= 2) f16_split(v, hi, lo);
+                    if (b3 == 3) {      // PrecH6: fp16 hi fragments only, [k16-step][64][8]; the fp6 lo part is packed on the device (pack_lo6_kernel)
+                        cb[((size_t)u * 64 + lane) * 8 + e] = hi;
+                        continue;
+                    }
                     cb[((size_t)(2 * u + 0) * 64 + lane) * 8 + e] = hi;
                     cb[((size_t)(2 * u + 1) * 64 + lane) * 8 + e] = lo;
                 }
@@ -209,6 +213,13 @@ int pack_and_upload(ag_model *m, const float *const *t)
     pack_layer(s, 2, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
     pack_layer(s, 2, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
     pack_layer(s, 2, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
+#ifdef AG_EXPERIMENTS
+    const size_t off_h6 = s.size();                                        // edge_encode stream, fp16 hi + block-scaled fp6 lo (edge_products 1: experiments/ag_mlp_h6.inc)
+    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], de - 3);
+    pack_layer(s, 3, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
+    pack_layer(s, 3, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
+    pack_layer(s, 3, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
+#endif
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
@@ -236,6 +247,30 @@ int pack_and_upload(ag_model *m, const float *const *t)
     m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
     m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
     m->w.edge_encode_h2 = reinterpret_cast<const float4 *>(m->dev + off_h2);
+#ifdef AG_EXPERIMENTS
+    m->w.edge_encode_h6 = reinterpret_cast<const float4 *>(m->dev + off_h6);
+    {   // fp6 part of the three wide layers: from the fp32 tensors, on the device (its conversion instruction defines the operand layout)
+        float *tmp = nullptr;
+        const size_t nW = (size_t)F * F, nRP = (size_t)F * 3 * F;
+        AG_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), (2 * nW + nRP + 3 * F) * sizeof(float)));
+        float *dW1 = tmp, *dW2 = tmp + nW, *dRP = tmp + 2 * nW, *dB = dRP + nRP;
+        hipError_t e = hipMemcpy(dW1, t[W_RE1], nW * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dW2, t[W_RE2], nW * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dRP, t[W_RP], nRP * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dB, t[B_RE1], F * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dB + F, t[B_RE2], F * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dB + 2 * F, t[B_RP], F * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            float *h6 = m->dev + off_h6;
+            ag_launch_pack_lo6(dW1, F, 0, F, F, dB, h6 + (size_t)1 * AG_CHUNK_FLOATS, nullptr);
+            ag_launch_pack_lo6(dW2, F, 0, F, F, dB + F, h6 + (size_t)(1 + AG_NT) * AG_CHUNK_FLOATS, nullptr);
+            ag_launch_pack_lo6(dRP, 3 * F, 0, F, F, dB + 2 * F, h6 + (size_t)(1 + 2 * AG_NT) * AG_CHUNK_FLOATS, nullptr);
+            e = hipDeviceSynchronize();
+        }
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(AG_ERR_HIP, "packing the fp6 weight images failed: %s", hipGetErrorString(e));
+    }
+#endif
     return AG_OK;
 }
 
@@ -420,6 +455,9 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
 #endif
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
+#ifdef AG_EXPERIMENTS
+    if (const char *v = getenv("AG_EDGE_PRODUCTS")) if (atoi(v) == 1) m->edge_products = 1;
+#endif
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
@@ -656,7 +694,12 @@ int ag_set_option(ag_model *m, const char *name, int value)
     }
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
-    else if (!strcmp(name, "edge_products")) m->edge_products = value == 3 ? 3 : 2;
+    else if (!strcmp(name, "edge_products")) {
+#ifndef AG_EXPERIMENTS
+        if (value == 1) return fail(AG_ERR_ARG, "edge_products 1 (block-scaled fp6 correction product) is compiled only into -DAG_EXPERIMENTS builds");
+#endif
+        m->edge_products = value == 3 ? 3 : (value == 1 ? 1 : 2);
+    }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);

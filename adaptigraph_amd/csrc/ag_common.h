@@ -48,6 +48,7 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *node_encode_b3, *edge_encode_b3, *node_mid_b3, *node_last_b3;
     // the edge stream as split-fp16 fragment images (same layout as the bf16 ones; precision mode 2, two-product edge stack)
     const float4 *edge_encode_h2;
+    const float4 *edge_encode_h6;   // the same stream for PrecH6: W_hi fp16 fragments + block-scaled fp6 W_lo per chunk (edge_products 1)
 };
 
 struct AgFwdArgs {
@@ -165,6 +166,7 @@ __device__ __forceinline__ void ag_reduce_node_half(const AgFwdArgs &a, int g, i
 
 // kernel launchers (one translation unit each)
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
+void ag_launch_pack_lo6(const float *W, int ld, int col0, int K, int n_out, const float *bias, float *chunks, hipStream_t s);
 void ag_launch_send_remap(const AgFwdArgs &a, hipStream_t s);
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s);

@@ -870,6 +870,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
 // ---------------------------------------------------------------------------------------------
 template <class Prec> constexpr int kEdgeWgPerCu = AG_MLP_WG_PER_CU;
 template <> constexpr int kEdgeWgPerCu<PrecH2> = AG_H2_WG_PER_CU;
+// weight stream of the edge stack per arithmetic, and whether its first-layer image carries the residual columns (f16_residual)
+template <class Prec> constexpr bool kEdgeResidualSlots = false;
+template <> constexpr bool kEdgeResidualSlots<PrecH2> = true;
+template <class Prec> __device__ __forceinline__ const float4 *edge_stream(const AgWeights &w) { return pick<Prec>(w.edge_encode, std::is_same_v<Prec, PrecH2> ? w.edge_encode_h2 : w.edge_encode_b3); }
+#ifdef AG_EXPERIMENTS
+#include "experiments/ag_mlp_h6.inc"      // PrecH6: the second product of PrecH2 on the block-scaled fp6 MFMA (edge_products 1)
+#endif
 template <class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
@@ -880,8 +887,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
-    const bool h2 = std::is_same_v<Prec, PrecH2>;
-    ChunkPipe P{pick<Prec>(w.edge_encode, h2 ? w.edge_encode_h2 : w.edge_encode_b3), 16, 0, 0, lds};
+    ChunkPipe P{edge_stream<Prec>(w), 16, 0, 0, lds};
     pipe_start(P);
     TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
 #if AG_TRACE
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
-        if constexpr (std::is_same<Prec, PrecH2>::value) {      // fp16 residuals of the position inputs in the spare K slots (see f16_residual)
+        if constexpr (kEdgeResidualSlots<Prec>) {      // fp16 residuals of the position inputs in the spare K slots (see f16_residual)
 #pragma unroll
             for (int q = 2; q < 4; ++q)
 #pragma unroll
@@ -1836,6 +1842,13 @@ void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     else hipLaunchKernelGGL((node_encode_kernel<PrecF32, false>), grid, block, 0, s, w, a);
 }
 
+#ifdef AG_EXPERIMENTS
+void ag_launch_pack_lo6(const float *W, int ld, int col0, int K, int n_out, const float *bias, float *chunks, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_lo6_kernel, dim3(AG_NT * 3), dim3(64), 0, s, W, ld, col0, K, n_out, bias, chunks);
+}
+#endif
+
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
@@ -1862,6 +1875,12 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     }
 #endif
     const dim3 block(AG_MLP_THREADS);
+#ifdef AG_EXPERIMENTS
+    if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 1) {     // mode 2 with the block-scaled fp6 correction product (PrecH6)
+        hipLaunchKernelGGL(edge_encode_kernel<PrecH6>, dim3(grid_for(a.e_cap, a.max_blocks)), block, 0, s, w, a);
+        return;
+    }
+#endif
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;

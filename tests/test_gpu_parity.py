@@ -357,6 +357,32 @@ def test_fused_segment_reduce_equals_the_separate_kernel(weights):
     assert torch.equal(m(*args, **kw)[1], p1)
 
 
+@pytest.mark.parametrize("name", ["fwd_rope301", "fwd_granular205", "fwd_trained_cloth_cloth257", "fwd_trained_rope_lr1e-2_rope64"])
+def test_block_scaled_fp6_correction_product_keeps_the_fast_modes_deviation(name, weights):
+    """(Experiment builds only.)  ag_set_option("edge_products", 1): the fast mode's second product W_lo . x runs as three block-scaled e2m3 MFMAs
+    (v_mfma_scale_f32_32x32x64_f8f6f4, operands converted by v_cvt_scalef32_2xpk16_fp6_f32) instead of ten fp16 ones: the deviation from the reference
+    forward stays that of the shipped two-product scheme (same gate and tolerance; the two agree within that tolerance), results are repeatable."""
+    g = load_golden(name)
+    material = str(g["material"])
+    m = make_model(weights_for(g, weights), material, 1.0, "fast")
+    try:
+        m.set_option("edge_products", 1)
+    except RuntimeError as e:              # the product library does not carry PrecH6 (csrc/experiments/ag_mlp_h6.inc, -DAG_EXPERIMENTS)
+        pytest.skip(str(e))
+    N = g["attrs"].shape[1]
+    csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw = {"action": t(g["action"]), material + "_physics_param": t(g["phys"])}
+    _, mot6 = m(*args, **kw)
+    assert np.abs(mot6.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC["fast"]
+    for _ in range(5):
+        assert torch.equal(m(*args, **kw)[1], mot6)
+    m.set_option("edge_products", 2)
+    _, mot2 = m(*args, **kw)
+    assert float((mot6 - mot2).abs().max()) <= TOL_BY_PREC["fast"]
+    assert m.take_status() & 1 == 0
+
+
 @pytest.mark.parametrize("case", ["rope_gap", "distinct_actions", "granular_tools", "cloth_padded", "ten_classes"])
 def test_node_encoder_deduplication_is_bitwise_the_per_node_encoder(weights, prec, case):
     """ag_set_option("node_dedup", 1) (default): particle_encode / Pn / the first round's Hr, Hs are computed once per distinct
