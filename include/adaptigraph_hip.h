@@ -61,6 +61,8 @@ int ag_model_destroy(ag_model *m);
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
  *   "edge_products"    2/3   precision 2 only: MFMAs per fp32 product in the EDGE stack: 2 = fp16 activations x split-fp16 weights (default;
  *                            models whose edge weights exceed the fp16 range keep 3), 3 = split-bf16 like precision 1
+ *                            (1 = the second of the two products on block-scaled fp6 MFMAs, same deviations: an experiment, compiled only into
+ *                            -DAG_EXPERIMENTS builds, csrc/experiments/ag_mlp_h6.inc; the product library refuses it)
  *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
  *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
  *   "node_dedup"       0/1/2 particle_encoder / hoisted Pn / the first round's Hr, Hs computed once per DISTINCT [attrs | phys | action] row of a sample

@@ -49,6 +49,37 @@ static float e4m3(unsigned char v)      // OCP e4m3fn
     return s ? -mag : mag;
 }
 
+// ---- (3) per-lane block scales on inexact data: the conversion builtin vs inline asm with an early-clobber destination ---------------
+// (through the builtin, hipcc of ROCm 7.2 may let the 6 destination registers overlap the SECOND source tuple; the instruction then converts
+//  values it has already overwritten.  Whether it does depends on the register allocation of the surrounding code.)
+template <bool ASM>
+__device__ __forceinline__ v8i chunk6(const v16f &a, const v16f &b)
+{
+    float m = 0.0f;
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(fabsf(a[r]), fabsf(b[r])));
+    int sb = (int)(__builtin_bit_cast(unsigned, m) >> 23) - 2;      // scale 2^(exponent(max) - 2): the block's largest value lands in [4, 8), saturating at 7.5
+    sb = sb < 1 ? 1 : sb;
+    const float scale = __builtin_bit_cast(float, (unsigned)sb << 23);
+    v6u q;
+    if constexpr (ASM) asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(q) : "v"(a), "v"(b), "v"(scale));
+    else q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a, b, scale);
+    return v8i{(int)q[0], (int)q[1], (int)q[2], (int)q[3], (int)q[4], (int)q[5], sb, 0};
+}
+template <bool ASM>
+__global__ void corr_once(const float *A, const float *B, v16f *D)      // A[32][64] (W_lo-like, +-1e-4), B[64][32] (ReLU'd activations)
+{
+    const int l = threadIdx.x, i = l & 31, h = l >> 5;
+    v16f a0, a1, b0, b1;
+    for (int r = 0; r < 16; ++r) {
+        a0[r] = A[i * 64 + 32 * h + r]; a1[r] = A[i * 64 + 32 * h + 16 + r];
+        b0[r] = B[(32 * h + r) * 32 + i]; b1[r] = B[(32 * h + 16 + r) * 32 + i];
+    }
+    const v8i qa = chunk6<ASM>(a0, a1), qb = chunk6<ASM>(b0, b1);
+    v16f acc = {};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qb, acc, 2, 2, 0, qa[6], 0, qb[6]);
+    D[l] = acc;
+}
+
 // ---- (2) rate ---------------------------------------------------------------------------------------------------------------
 template <int FMT>      // -1: f16 32x32x16;  0 fp8, 2 fp6, 4 fp4: MX 32x32x64
 __global__ __launch_bounds__(256, 2) void rate(const v8i *g, float *out, int iters, int sc)
@@ -144,6 +175,31 @@ int main()
             }
         printf("fp6 e2m3 x e2m3 via v_cvt_scalef32_2xpk16_fp6_f32 (scale 1.0), per-lane scales: max |D - cpu| = %.3e (max |D| %.1f) -> %s\n", worst, mag,
                worst <= 1e-4 * mag ? "CONFIRMED" : "WRONG");
+    }
+    // ---------------- (3) a W_lo . x correction product with per-lane block scales
+    {
+        std::vector<float> A(32 * 64), B(64 * 32);
+        auto uni = [&] { return rnd() / 16777216.0f; };
+        for (auto &v : A) v = (uni() - 0.5f) * 2e-4f * (uni() < 0.3f ? 0.1f : 1.0f);
+        for (auto &v : B) { const float g = (uni() + uni() + uni() - 1.5f) * 2.0f; v = g > 0 ? g : 0.0f; }
+        float *dA, *dB; v16f *dD;
+        hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dD, 64 * 64);
+        hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        for (int use_asm = 0; use_asm < 2; ++use_asm) {
+            if (use_asm) hipLaunchKernelGGL(corr_once<true>, dim3(1), dim3(64), 0, 0, dA, dB, dD); else hipLaunchKernelGGL(corr_once<false>, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+            std::vector<float> D(64 * 16);
+            hipMemcpy(D.data(), dD, 64 * 64, hipMemcpyDeviceToHost);
+            double num = 0, den = 0;
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 16; ++r) {
+                    const int col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                    double ref = 0;
+                    for (int kk = 0; kk < 64; ++kk) ref += (double)A[row * 64 + kk] * B[kk * 32 + col];
+                    num += (D[l * 16 + r] - ref) * (D[l * 16 + r] - ref); den += ref * ref;
+                }
+            printf("fp6 correction product, per-lane scales from the block maxima, conversion via %s: rms relative error %.3f\n",
+                   use_asm ? "inline asm (early-clobber destination)" : "the builtin", sqrt(num / den));
+        }
     }
     // ---------------- (2) sustained rate, random operands
     {
