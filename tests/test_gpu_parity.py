@@ -361,7 +361,8 @@ def test_fused_segment_reduce_equals_the_separate_kernel(weights):
 def test_block_scaled_fp6_correction_product_keeps_the_fast_modes_deviation(name, weights):
     """(Experiment builds only.)  ag_set_option("edge_products", 1): the fast mode's second product W_lo . x runs as three block-scaled e2m3 MFMAs
     (v_mfma_scale_f32_32x32x64_f8f6f4, operands converted by v_cvt_scalef32_2xpk16_fp6_f32) instead of ten fp16 ones: the deviation from the reference
-    forward stays that of the shipped two-product scheme (same gate and tolerance; the two agree within that tolerance), results are repeatable."""
+    forward stays that of the shipped two-product scheme (same gate and tolerance; the two agree within that tolerance), results are repeatable, and the
+    two experiment kernels that implement it (eight-wave weight-stationary, streaming) agree bit for bit."""
     g = load_golden(name)
     material = str(g["material"])
     m = make_model(weights_for(g, weights), material, 1.0, "fast")
@@ -373,10 +374,13 @@ def test_block_scaled_fp6_correction_product_keeps_the_fast_modes_deviation(name
     csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
     args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
     kw = {"action": t(g["action"]), material + "_physics_param": t(g["phys"])}
-    _, mot6 = m(*args, **kw)
+    _, mot6 = m(*args, **kw)                  # edge_stationary 1 (default): the eight-wave weight-stationary kernel (experiments/ag_mlp_ws8.inc)
     assert np.abs(mot6.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC["fast"]
     for _ in range(5):
         assert torch.equal(m(*args, **kw)[1], mot6)
+    m.set_option("edge_stationary", 0)        # the streaming kernel with the same arithmetic (experiments/ag_mlp_h6.inc): bit for bit
+    assert torch.equal(m(*args, **kw)[1], mot6)
+    m.set_option("edge_stationary", 1)
     m.set_option("edge_products", 2)
     _, mot2 = m(*args, **kw)
     assert float((mot6 - mot2).abs().max()) <= TOL_BY_PREC["fast"]
