@@ -1877,16 +1877,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 #endif
     const dim3 block(AG_MLP_THREADS);
 #ifdef AG_EXPERIMENTS
-    if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 1) {     // mode 2 with the block-scaled fp6 correction product (PrecH6)
-        if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // eight-wave weight-stationary kernel
-            const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
-            hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(edge_encode_ws8_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);
-            return;
-        }
-        hipLaunchKernelGGL(edge_encode_kernel<PrecH6>, dim3(grid_for(a.e_cap, a.max_blocks)), block, 0, s, w, a);
-        return;
-    }
+    if (ag_launch_edge_encode_h6(w, a, s)) return;      // edge_products 1: the block-scaled fp6 correction product (experiments/ag_mlp_ws8.inc)
 #endif
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
