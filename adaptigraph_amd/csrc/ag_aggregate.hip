@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 
 }  // namespace
 #if defined(AG_EXPERIMENTS) && AGS_TRACE
-extern "C" int ag_debug_agg_trace(unsigned long long *out, int reset)
+extern "C" __attribute__((visibility("default"))) int ag_debug_agg_trace(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ags_trace), sizeof(ags_trace)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ags_trace), z, sizeof z) != hipSuccess) return -1; }

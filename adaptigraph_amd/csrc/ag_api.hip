@@ -459,7 +459,9 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) if (atoi(v) == 1) m->edge_products = 1;
 #endif
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
+#ifdef AG_EXPERIMENTS
     if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
+#endif
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
     {
         int dev = 0;
@@ -701,7 +703,12 @@ int ag_set_option(ag_model *m, const char *name, int value)
         m->edge_products = value == 3 ? 3 : (value == 1 ? 1 : 2);
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
-    else if (!strcmp(name, "aggregate_stream")) m->agg_stream = value != 0;
+    else if (!strcmp(name, "aggregate_stream")) {
+#ifndef AG_EXPERIMENTS
+        if (value != 0) return fail(AG_ERR_ARG, "ag_set_option: aggregate_stream %d is an experiment (build with -DAG_EXPERIMENTS, csrc/experiments/)", value);
+#endif
+        m->agg_stream = value != 0;
+    }
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "edge_rows")) {
 #ifndef AG_EXPERIMENTS

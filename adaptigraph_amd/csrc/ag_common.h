@@ -96,7 +96,7 @@ struct AgFwdArgs {
     const int32_t *hr_row;           // segment reduce: row of Hr to read for node g (NULL: g) — node_row in round 0
     const float *pn_rows;            // node_update: Pn from compact rows pn_rows[node_row[g]] (NULL: packed table pn)
     const float *h_rows;             // node_update, round 0: residual h from compact rows (NULL: packed table h)
-    int agg_stream;    // precision mode 2: 1 = streamed segment reduce (aggregate_stream_kernel: Eterm rows + sender indices through an LDS-DMA ring, default), 0 = aggregate_half_kernel
+    int agg_stream;    // -DAG_EXPERIMENTS builds only: 1 = streamed segment reduce (experiments/ag_aggregate_stream.inc, measured slower); the product always runs aggregate_half_kernel
     int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
                        // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };

@@ -1810,7 +1810,7 @@ __global__ __launch_bounds__(256) void train_pack_b3_kernel(const float *W, cons
 }  // namespace
 
 #if AG_TRACE
-extern "C" int ag_debug_trace_read(unsigned long long *dst)
+extern "C" __attribute__((visibility("default"))) int ag_debug_trace_read(unsigned long long *dst)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ag_trace_buf), sizeof(unsigned long long) * 4 * 512);
 }

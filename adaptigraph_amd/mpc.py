@@ -2,8 +2,9 @@
 
 `running_cost` is a drop-in for src/planning/plan.py:27-59; `MPPIPlanner.trajectory_optimization_mppi` follows
 src/planning/real_world/planner.py:234-277 (sample -> rollout -> evaluate -> softmax update -> keep the best sample),
-with the rollout sharded over the ranks of the process group when one is initialised.  Everything stays on the GPU: an
-iteration has no host read at all (the reference's `error.max().item()` normaliser is a 0-d tensor here).
+with the rollout sharded over the ranks of the process group when one is initialised.  Everything stays on the GPU: `running_cost`
+and `Planner`'s iteration read nothing back (the reference's `error.max().item()` normaliser is a 0-d tensor here and the best
+sample is picked with a device-side `index_select`, not with a 0-d tensor index, which PyTorch resolves through `.item()`).
 """
 import functools
 
@@ -107,12 +108,13 @@ class Planner:
             eval_out = self.evaluate_traj(model_out["state_seqs"], act_seqs, state_cur=state_cur, weights=model_out.get("weights"))
             reward = eval_out["reward_seqs"]
             act_seq = self.optimize_action(act_seqs, reward)
-            k = torch.argmax(reward)
+            k = torch.argmax(reward).reshape(1)    # stays on the device: indexing with a 0-d tensor would go through .item() (a host sync)
+            seq_k, reward_k = act_seqs.index_select(0, k)[0], reward.index_select(0, k)[0]
             if i == 0:
-                best_seq, best_reward = act_seqs[k], reward[k]
+                best_seq, best_reward = seq_k, reward_k
             else:                                   # keep the better of the two without reading the comparison back
-                better = reward[k] > best_reward
-                best_seq, best_reward = torch.where(better, act_seqs[k], best_seq), torch.where(better, reward[k], best_reward)
+                better = reward_k > best_reward
+                best_seq, best_reward = torch.where(better, seq_k, best_seq), torch.where(better, reward_k, best_reward)
             if self.verbose:
                 model_outputs.append(model_out)
                 eval_outputs.append(eval_out)
@@ -146,8 +148,10 @@ class MPPIPlanner:
         self.reward_weight, self.noise_level, self.push_length = reward_weight, noise_level, task["push_length"]
         self.rollout_best = rollout_best
         self.model = model
-        self.n_sample_chunk = n_sample_chunk      # None: all samples in ONE rollout (the engine has no memory reason to chunk);
-                                                   # an int reproduces the reference's chunked evaluation (rope.yaml:41-42: 20 000 in chunks of 500)
+        self.n_sample_chunk = n_sample_chunk      # None: all samples in ONE rollout (the engine has no memory reason to chunk).  An int only
+                                                   # chunks the ROLLOUT's memory: cost normaliser and softmax update still see all samples at once.
+                                                   # The reference's chunked planner (rope.yaml:41-42: 20 000 in chunks of 500) is different: an
+                                                   # independent Planner per chunk + merge_res — use mpc.Planner per chunk for those semantics.
         self.model_rollout = lambda state, acts: dynamics_sharded(dynamics, state, acts, model, device, ppm_optimizer)
         self.evaluate_traj = functools.partial(running_cost, error_func=error_func, penalty_func=penalty_func, bbox=bbox)
 
@@ -178,9 +182,13 @@ class MPPIPlanner:
         for i in range(self.n_update_iter):
             act_seqs = self.sample(act_seq, i, sample_device)
             act_seq, reward, _ = self.step(state_cur, act_seqs)
-            k = torch.argmax(reward)
-            if best_reward is None or reward[k] > best_reward:
-                best_seq, best_reward = act_seqs[k], reward[k]
+            k = torch.argmax(reward).reshape(1)
+            seq_k, reward_k = act_seqs.index_select(0, k)[0], reward.index_select(0, k)[0]
+            if best_reward is None:
+                best_seq, best_reward = seq_k, reward_k
+            else:
+                better = reward_k > best_reward
+                best_seq, best_reward = torch.where(better, seq_k, best_seq), torch.where(better, reward_k, best_reward)
         res = {"act_seq": best_seq, "best_reward": best_reward}
         if self.rollout_best:
             out = self.model_rollout(state_cur, best_seq[None])

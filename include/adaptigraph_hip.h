@@ -22,6 +22,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and the pop at the end of the
+ * header are exported (tests/test_abi.py holds `nm -D` to that list). */
+#pragma GCC visibility push(default)
 
 typedef struct ag_model ag_model;
 typedef void *ag_stream_t; /* hipStream_t */
@@ -241,6 +244,7 @@ enum { AG_K_EDGES = 0, AG_K_NODE_ENCODE = 1, AG_K_EDGE_ENCODE = 2, AG_K_AGGREGAT
 int ag_profile_enable(ag_model *m, int enable);
 int ag_profile_read(ag_model *m, double *ms /*AG_K_COUNT*/, int64_t *launches /*AG_K_COUNT*/, int64_t *edges);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == names
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """-fvisibility=hidden + csrc/exports.map: `nm -D` shows the declared ag_* functions and nothing else (no mangled launchers,
+    no template instantiations, no __hip_cuid_* words)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.check_output([nm, "-D", "--defined-only", _lib.build()], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols()
+
+
 def test_version_and_capacity_queries():
     L = _lib.lib()
     assert L.ag_version() >= 1

@@ -103,8 +103,10 @@ def _gloo_worker(rank, world, port, total, q):
             return {"state_seqs": seq, "action_seqs": act * 2}
 
         out = agdist.dynamics_sharded(fake_dynamics, state, action, "x")
+        local = list(calls)                   # the shard this rank rolled out (nothing at all when there are more ranks than samples)
         full = fake_dynamics(state, action, "x")
-        ok = all(torch.equal(out[k], full[k]) for k in full) and calls[0] <= (total + world - 1) // world
+        lo, hi, per = agdist.shard_bounds(total, rank, world)
+        ok = all(torch.equal(out[k], full[k]) for k in full) and local == ([hi - lo] if hi > lo else []) and hi - lo <= per
         # a second call reuses the cached collective buffers; the first result must not be overwritten (copy semantics)
         out2 = agdist.dynamics_sharded(fake_dynamics, state, action + 1.0, "x")
         full2 = fake_dynamics(state, action + 1.0, "x")
@@ -126,15 +128,26 @@ def _gloo_worker(rank, world, port, total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 5, 1])
-def test_dynamics_sharded_gloo_world2(total):
+def _run_gloo(world, total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000 + total
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world * 131 + total) % 3000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("total", [8, 5, 1])
+def test_dynamics_sharded_gloo_world2(total):
+    _run_gloo(2, total)
+
+
+@pytest.mark.parametrize("world,total", [(4, 10), (8, 1024), (8, 500), (8, 3)])
+def test_dynamics_sharded_gloo_world4_and_8(world, total):
+    """The SCALE run's shapes before the first real RCCL contact: BASELINE configs[4]'s 1024 samples over 8 ranks (even), 500 over 8
+    (uneven: seven shards of 63 and one of 59), fewer samples than ranks (empty shards), and a 4-rank uneven split."""
+    _run_gloo(world, total)

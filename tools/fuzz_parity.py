@@ -12,11 +12,12 @@ from adaptigraph_amd import configs, synth
 from adaptigraph_amd import graph as aggraph
 from adaptigraph_amd.model import DynamicsPredictor
 from oracle import ag_oracle as ago
+from fuzz_cases import gen_cases
 
 DEV = "cuda:0"
 GATE = 1e-4
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only_prec = int(sys.argv[3]) if len(sys.argv) > 3 else None
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 W = {"seed0": load_golden("weights_seed0")}
@@ -37,38 +38,13 @@ def model(mat, wname, prec, dedup):
     return m
 
 
-def loguniform(lo, hi):
-    return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
-
-
 worst = {0: 0.0, 1: 0.0, 2: 0.0}
 worst_rel = {0: 0.0, 1: 0.0, 2: 0.0}      # deviation / max(|reference motion|) of the case
 fails = 0
 flagged = 0
-for c in range(cases):
-    mat = ("rope", "granular", "cloth")[rng.integers(3)]
-    if mat == "cloth":
-        side = loguniform(1, 45); n_obj = side * side
-    else:
-        n_obj = loguniform(1, 2500 if mat == "granular" else 1500)
-    batch = int(rng.integers(1, 6))
-    n_pad = int(rng.integers(0, 10)) if rng.random() < 0.5 else 0
-    kw = dict(spacing=float(rng.choice([0.03, 0.1, 0.3]))) if mat == "rope" else (dict(tool_near=bool(rng.random() < 0.7)) if mat == "cloth" else {})
-    g = synth.make_graph_inputs(mat, n_obj, batch, seed=int(rng.integers(1 << 30)), n_pad=n_pad, **kw)
+for case in gen_cases(cases, seed, only_prec):
+    mat, g, prec, dedup, wname, variant, tag = (case[k] for k in ("mat", "g", "prec", "dedup", "wname", "variant", "tag"))
     mm = synth.MATERIALS[mat]
-    n_p, N = g["n_p"], g["attrs"].shape[1]
-    if rng.random() < 0.4:                    # invalidate random object slots (a ragged cloud: mask False, no instance, no attribute)
-        drop = rng.random((batch, n_obj)) < rng.uniform(0.02, 0.3)
-        g["mask"][:, :n_obj] &= ~drop
-        g["p_instance"][:, :n_obj, 0] *= ~drop
-        g["attrs"][:, :n_obj, 0] *= ~drop
-    if rng.random() < 0.5:                    # per-sample physics parameter and tool action
-        g["phys"] = rng.uniform(0.0, 1.0, g["phys"].shape).astype(np.float32)
-        amax = float(rng.choice([0.1, 0.2, 0.5]))
-        g["action"][:, n_p:] = rng.uniform(-amax, amax, (batch, N - n_p, 3)).astype(np.float32)
-    prec = int(rng.integers(3)) if only_prec is None else only_prec; dedup = int(rng.choice([0, 2])); wname = str(rng.choice(["seed0", mat]))
-    variant = "batch" if rng.random() < 0.8 else "single"
-    tag = f"case {c}: {mat} n_obj {n_obj} batch {batch} pad {n_pad} {kw} prec {prec} dedup {dedup} weights {wname} {variant}"
     pos_now = g["state"][:, -1]
     n_rel, recv, send = ago.build_edges(pos_now, mm["radius"], g["mask"], g["tool_mask"], mm["topk"], mm["connect_tools_all"], variant)
     csr = aggraph.build_edges(t(pos_now), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"], mm["connect_tools_all"], variant,

@@ -1,0 +1,210 @@
+"""CPU study (float64 emulation, no GPU): deviation of candidate edge-stack / per-edge-table arithmetics from the exact forward on the
+random case stream of tools/fuzz_parity.py (same generator, same seeds: tools/fuzz_cases.py) — the cases where the r03 default mode
+measured up to 1.43e-4 on the GPU.  Node-level layers stay exact here (their split-bf16 arithmetic measures <= 8e-6 on every case).
+    python tools/scheme_err.py [cases=200] [seed=11] [max_obj=2500] [only cases with tool actions: 0/1]"""
+import os, sys
+import numpy as np, torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from conftest import load_golden
+from adaptigraph_amd import synth
+from oracle import ag_oracle as ago
+from fuzz_cases import gen_cases
+
+torch.set_num_threads(8)
+WN = {"seed0": load_golden("weights_seed0")}
+for mat in ("rope", "granular", "cloth"):
+    WN[mat] = load_golden("weights_trained_" + mat)
+h16 = lambda x: x.half().double()
+ident = lambda v: v
+
+
+def split16(x):      # x = x16 + r16, both fp16 (what a three-product fp16 stack sees)
+    a = h16(x)
+    return a + h16(x - a)
+
+
+def to_blocks(x):
+    """(..., F<=160) -> (..., 3 tile pairs, 2 h, 32): the K block of a lane (j, h) of the block-scaled MFMA is tiles 2c, 2c+1 of its own
+    accumulator image: features 32t + 8q + 4h + p."""
+    pad = 192 - x.shape[-1]
+    x = F.pad(x, (0, pad))
+    x = x.reshape(*x.shape[:-1], 3, 2, 4, 2, 4)          # c, t2, q, h, p
+    x = x.permute(*range(x.dim() - 5), -5, -2, -4, -3, -1)   # c, h, t2, q, p
+    return x.reshape(*x.shape[:-3], 32)
+
+
+def from_blocks(b, Fdim):
+    x = b.reshape(*b.shape[:-1], 2, 4, 4)                  # c, h, t2, q, p
+    x = x.permute(*range(x.dim() - 5), -5, -3, -2, -4, -1)   # c, t2, q, h, p
+    return x.reshape(*x.shape[:-5], 192)[..., :Fdim]
+
+
+def fp6_e2m3(v):
+    """round-to-nearest-even onto the E2M3 grid, saturating at 7.5"""
+    a = v.abs().clamp(max=7.5)
+    step = torch.where(a < 2.0, 0.125, torch.where(a < 4.0, 0.25, 0.5))
+    q = torch.round(a / step) * step          # torch.round is half-to-even
+    return torch.sign(v) * q.clamp(max=7.5)
+
+
+def q_fp6_blocks(x):
+    """block-scaled fp6: per 32-element K block a power-of-two scale 2^(exponent(max) - 2)"""
+    Fdim = x.shape[-1]
+    b = to_blocks(x)
+    mx = b.abs().amax(-1, keepdim=True).clamp(min=1e-300)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) - 2)
+    return from_blocks(fp6_e2m3(b / sc) * sc, Fdim)
+
+
+def q_int_tile(x, bits=16):
+    """block fixed point per 32-feature out-tile of an edge row (both lane halves share the scale): snorm16 against a power-of-two block scale"""
+    Fdim = x.shape[-1]
+    b = F.pad(x, (0, 160 - Fdim)).reshape(*x.shape[:-1], 5, 32)
+    mx = b.abs().amax(-1, keepdim=True).clamp(min=1e-300)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) + 1)                    # 2^e > max
+    q = torch.round(b / sc * (2 ** (bits - 1) - 1)) / (2 ** (bits - 1) - 1) * sc
+    return q.reshape(*x.shape[:-1], 160)[..., :Fdim]
+
+
+def q_bf8(v, pre):
+    """E5M2 (3 significant bits, RNE, subnormals below 2^-14) of v * 2^pre, returned unscaled"""
+    a = v * 2.0 ** pre
+    e = torch.floor(torch.log2(a.abs().clamp(min=1e-300))).clamp(min=-14)
+    step = torch.exp2(e - 2)
+    return torch.round(a / step) * step / 2.0 ** pre
+
+
+def q_int_block(x, bits, block):
+    """block fixed point: blocks of `block` consecutive features in accumulator order of one (tile, h); power-of-two scale from the block maximum"""
+    Fdim = x.shape[-1]
+    b = to_blocks(x)                                  # (..., 3, 2, 32): t2, q, p inside
+    b = b.reshape(*b.shape[:-1], 32 // block, block)
+    mx = b.abs().amax(-1, keepdim=True).clamp(min=1e-300)
+    e = torch.ceil(torch.log2(mx * (1 + 2.0 ** -(bits - 1))))          # 2^e > max (so that max rounds inside the range)
+    step = torch.exp2(e - (bits - 1))
+    q = torch.round(b / step).clamp(-(2 ** (bits - 1)), 2 ** (bits - 1) - 1) * step
+    return from_blocks(q.reshape(*q.shape[:-2], 32), Fdim)
+
+
+class Scheme:
+    """lin(x, w, b, layer) for the four edge-stack layers + the table rounding"""
+    def __init__(self, name, kind, table=ident, res_cols=3):
+        self.name, self.kind, self.table, self.res_cols = name, kind, table, res_cols
+
+    def lin(self, x, w, b, layer):
+        k = self.kind
+        if k == "exact":
+            return F.linear(x, w, b)
+        if k == "x16":           # shipped mode 2: one fp16 activation, split weights (exact here); layer 0 carries residuals of the last res_cols inputs
+            xe = h16(x)
+            if layer == 0 and self.res_cols:
+                xe[:, -self.res_cols:] = xe[:, -self.res_cols:] + h16(x[:, -self.res_cols:] - xe[:, -self.res_cols:])
+            return F.linear(xe, w, b)
+        if k == "x16x2":         # three fp16 products: x = x16 + r16
+            return F.linear(split16(x), w, b)
+        if k == "x16+r6":        # two fp16 products + block-scaled fp6 correction  fp6(W) . fp6(x - x16)   (layer 0: fp16 residual slots as shipped)
+            xe = h16(x)
+            if layer == 0:
+                xe[:, -3:] = xe[:, -3:] + h16(x[:, -3:] - xe[:, -3:])
+                return F.linear(xe, w, b)
+            return F.linear(xe, w, b) + F.linear(q_fp6_blocks(x - xe), q_fp6_blocks(w))
+        if k == "x16+r8":        # two fp16 products + bf8(W 2^-6) . bf8((x - x16) 2^6) on the fp8 MFMA; layer 0: residual slots for all 12 state inputs
+            xe = h16(x)
+            if layer == 0:
+                xe[:, -12:] = xe[:, -12:] + h16(x[:, -12:] - xe[:, -12:])
+                return F.linear(xe, w, b)
+            return F.linear(xe, w, b) + F.linear(q_bf8(x - xe, 6), q_bf8(w, -6))
+        if k == "x16+r8t":       # THREE fp16 products, the third on r8 = top byte (sign, exponent, 2 mantissa bits: truncation) of fp16(x - x16); layer 0: 12 residual slots
+            xe = h16(x)
+            if layer == 0:
+                xe[:, -12:] = xe[:, -12:] + h16(x[:, -12:] - xe[:, -12:])
+                return F.linear(xe, w, b)
+            if self.res_cols == 99:      # RNE to E5M2 instead of truncation (v_cvt_pk_bf8_f32)
+                return F.linear(xe + q_bf8(x - xe, 0), w, b)
+            r = (x - xe).half().view(torch.int16).bitwise_and(-256).view(torch.float16).double()
+            return F.linear(xe + r, w, b)
+        if k == "x16x2r12":      # three fp16 products, layer 0 with residual slots for all 12 state inputs
+            if layer == 0:
+                xe = h16(x); xe[:, -12:] = xe[:, -12:] + h16(x[:, -12:] - xe[:, -12:])
+                return F.linear(xe, w, b)
+            return F.linear(split16(x), w, b)
+        if k == "fp6all":        # W_hi . x16 + fp6(W_lo) . fp6(x16) + fp6(W_hi) . fp6(x - x16)
+            xe = h16(x); wh = h16(w)
+            if layer == 0:
+                xe[:, -3:] = xe[:, -3:] + h16(x[:, -3:] - xe[:, -3:])
+                return F.linear(xe, w, b)
+            return F.linear(xe, wh, b) + F.linear(q_fp6_blocks(xe), q_fp6_blocks(w - wh)) + F.linear(q_fp6_blocks(x - xe), q_fp6_blocks(wh))
+        raise ValueError(k)
+
+
+def forward(W, g, n_rel, recv, send, sch):
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).double()
+    state, attrs, action, p_inst, phys = t("state"), t("attrs"), t("action"), t("p_instance"), t("phys")
+    B, N = attrs.shape[:2]; n_p = p_inst.shape[1]
+    sn = torch.cat([state[:, 1:] - state[:, :-1], state[:, -1:]], 1).transpose(1, 2).reshape(B, N, -1)
+    ph = torch.cat([phys[:, None].expand(B, n_p, -1), phys.new_zeros(B, N - n_p, phys.shape[1])], 1)
+    p_in = torch.cat([attrs, ph, action], 2)
+    grp = torch.cat([p_inst, p_inst.new_zeros(B, N - n_p, p_inst.shape[2])], 1)
+    out = []
+    for b in range(B):
+        n = int(n_rel[b]); r = torch.from_numpy(recv[b, :n].astype("int64")); s = torch.from_numpy(send[b, :n].astype("int64"))
+        rel = torch.cat([attrs[b, r], attrs[b, s], (grp[b, r] - grp[b, s]).abs().sum(1, keepdim=True), sn[b, r] - sn[b, s]], 1)
+        x = p_in[b]
+        for i in (0, 2, 4): x = F.relu(F.linear(x, W[f"particle_encoder.model.{i}.weight"], W[f"particle_encoder.model.{i}.bias"]))
+        enc_n = x
+        x = rel
+        for li, i in enumerate((0, 2, 4)):
+            x = F.relu(sch.lin(x, W[f"relation_encoder.model.{i}.weight"], W[f"relation_encoder.model.{i}.bias"], li))
+        wrp, brp = W["relation_propagator.linear.weight"], W["relation_propagator.linear.bias"]
+        wpp, bpp = W["particle_propagator.linear.weight"], W["particle_propagator.linear.bias"]
+        eterm = sch.table(sch.lin(x, wrp[:, :150], brp, 3))
+        hcur = enc_n
+        pn = F.linear(enc_n, wpp[:, :150], bpp)
+        for _ in range(3):
+            hr_t, hs_t = F.linear(hcur, wrp[:, 150:300]), F.linear(hcur, wrp[:, 300:])
+            eff = F.relu(eterm + hr_t[r] + hs_t[s])
+            agg = torch.zeros(N, 150, dtype=torch.float64).index_add_(0, r, eff)
+            hcur = F.relu(pn + F.linear(agg, wpp[:, 150:]) + hcur)
+        x = hcur[:n_p]
+        x = F.relu(F.linear(x, W["non_rigid_predictor.linear_0.weight"], W["non_rigid_predictor.linear_0.bias"]))
+        x = F.relu(F.linear(x, W["non_rigid_predictor.linear_1.weight"], W["non_rigid_predictor.linear_1.bias"]))
+        out.append(F.linear(x, W["non_rigid_predictor.linear_2.weight"], W["non_rigid_predictor.linear_2.bias"]))
+    return torch.stack(out).numpy()
+
+
+SCHEMES = [
+    Scheme("M2 (shipped r03: x fp16 + fp16 table)", "x16", h16),
+    Scheme("exact stack + snorm16 per tile", "exact", q_int_tile),
+    Scheme("x16 + top-byte residual (3rd fp16 product) + snorm16/tile", "x16+r8t", q_int_tile),
+    Scheme("x16 + e5m2(RNE) residual (3rd fp16 product) + snorm16/tile", "x16+r8t", q_int_tile, res_cols=99),
+    Scheme("x16 + e5m2(RNE) residual (3rd fp16 product) + fp16 table", "x16+r8t", h16, res_cols=99),
+]
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+    max_obj = int(sys.argv[3]) if len(sys.argv) > 3 else 2500
+    only_act = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    worst = {s.name: (0.0, "") for s in SCHEMES}
+    n = 0
+    for case in gen_cases(cases, seed, 2, max_obj=max_obj):
+        mat, g, wname, variant = case["mat"], case["g"], case["wname"], case["variant"]
+        if only_act and (float(np.abs(g["action"]).max()) <= 0.11 or wname == "seed0"):
+            continue
+        mm = synth.MATERIALS[mat]
+        n_rel, recv, send = ago.build_edges(g["state"][:, -1], mm["radius"], g["mask"], g["tool_mask"], mm["topk"], mm["connect_tools_all"], variant)
+        W = {k: torch.from_numpy(v).double() for k, v in WN[wname].items()}
+        ref = forward(W, g, n_rel, recv, send, Scheme("exact", "exact"))
+        mag = float(np.abs(ref).max())
+        line = []
+        for s in SCHEMES:
+            e = float(np.abs(forward(W, g, n_rel, recv, send, s) - ref).max())
+            line.append(e)
+            if e > worst[s.name][0]: worst[s.name] = (e, case["tag"] + f" |motion| {mag:.3f}")
+        n += 1
+        print(f"{case['c']:4d} |m| {mag:.3f} " + " ".join(f"{e:.2e}" for e in line) + "  " + case["tag"].split(": ", 1)[1], flush=True)
+    print(f"--- {n} cases (seed {seed})")
+    for s in SCHEMES:
+        print(f"{s.name:48s} worst {worst[s.name][0]:.2e}   {worst[s.name][1]}")
