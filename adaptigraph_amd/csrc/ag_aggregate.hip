@@ -63,69 +63,32 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     if (a.status && !isfinite((acc.x + acc.y) + (acc.z + acc.w))) atomicOr(a.status, 1);
 }
 
-// Same reduction with Eterm stored as fp16 in accumulator order (precision mode 2: half the dominant HBM stream).
-// A row is 160 halves = 20 x 16 B; thread c of a node owns half-positions [8c, 8c+8) = features
-// f0 = 32t + 8q0 + 4h + {0..3} and f0 + 8 (t = c/4, h = (c%4)/2, q0 = 2*(c%2)).
-// A node has ~10 edges and every edge costs a dependent index -> row round trip, so FOUR edges are kept in flight per
-// lane and the sender indices of the next four are fetched one iteration ahead (the adds still run in ascending edge
-// order: bit-identical to a sequential loop).  Measured 0.303 -> 0.292 ms vs two in flight; nontemporal Eterm loads: worse.
-constexpr int kNodesPerBlockH = 12;   // 12 nodes x 20 lanes = 240 of 256 lanes busy
+// Same reduction over the 16-bit table of precision mode 2 (q16, ag_common.h: half the dominant HBM stream).  A row is 20 x 16 B; twenty
+// adjacent lanes of one wave own a node, three nodes per wave, twelve per workgroup (240 of 256 lanes busy).
+constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 
 __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 {
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tid = threadIdx.x;
-    if (tid >= kNodesPerBlockH * 20) return;
-    const int slot = tid / 20, c = tid - slot * 20;
-    const int g = logical * kNodesPerBlockH + slot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / AG_AGG_GROUP, c = lane - grp * AG_AGG_GROUP;
+    if (grp >= AG_AGG_NODES_PER_WAVE) return;
+    const int g = logical * kNodesPerBlockH + wave * AG_AGG_NODES_PER_WAVE + grp;
     if (g >= a.B * a.N) return;
     float4 acc0, acc1;
-    ag_reduce_node_half(a, g, c, acc0, acc1);
+    ag_reduce_node_q16(a, g, c, grp * AG_AGG_GROUP, acc0, acc1);
     const int f0 = ag_half_lane_feature(c);
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0) = acc0;
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
 }
 
-
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_aggregate_stream.inc"
-#endif
-
 }  // namespace
-#if defined(AG_EXPERIMENTS) && AGS_TRACE
-extern "C" __attribute__((visibility("default"))) int ag_debug_agg_trace(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ags_trace), sizeof(ags_trace)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(ags_trace), z, sizeof z) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
 
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s)
 {
     const int nodes = a.B * a.N;
-#ifdef AG_EXPERIMENTS
-    if (a.eterm_half && a.agg_stream && (size_t)nodes * AG_FP * sizeof(float) < (1ull << 32)) {
-        int grid = (a.max_blocks > 0 ? a.max_blocks : 512) / AG_MLP_WG_PER_CU * AGS_WGPC;     // a.max_blocks = this launch's share of the chip, in MLP workgroups (2 per CU)
-        int per = (nodes + grid - 1) / grid;
-#ifdef AGS_NODES
-        per = AGS_NODES;
-#endif
-        if (per < 3 * AGS_W) per = 3 * AGS_W;
-        grid = (nodes + per - 1) / per;
-        hipLaunchKernelGGL(aggregate_stream_kernel, dim3(grid), dim3(64 * (AGS_W + 1)), 0, s, a, per);
-        return;
-    }
-#ifdef AGP_ON
-    if (a.eterm_half) {
-        const int nblk = (nodes + kNodesPerBlockH - 1) / kNodesPerBlockH;
-        hipLaunchKernelGGL(aggregate_half_range_kernel, dim3((nblk + AGP_BLOCKS - 1) / AGP_BLOCKS), dim3(256), 0, s, a);
-        return;
-    }
-#endif
-#endif   // AG_EXPERIMENTS
     if (a.eterm_half) {
         hipLaunchKernelGGL(aggregate_half_kernel, dim3((nodes + kNodesPerBlockH - 1) / kNodesPerBlockH), dim3(256), 0, s, a);
         return;

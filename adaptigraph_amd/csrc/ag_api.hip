@@ -150,21 +150,18 @@ struct ag_model {
     size_t dev_floats = 0;
     AgWeights w{};
     // optional profiling (ag_profile_enable): event pairs per kernel class, recorded on the caller's stream
-    int fuse_agg = 0;           // segment reduce inside node_update (env AG_FUSE_AGG / "fuse_aggregate"): 1 = row-per-lane in the MFMA layout (r01,
-                                // measured slower), 2 = cooperative LDS-staged reduce (precision mode 2 only; other modes keep the launch)
+    int fuse_agg = 0;           // segment reduce inside node_update (env AG_FUSE_AGG / "fuse_aggregate"): 2 = cooperative LDS-staged reduce
+                                // (precision mode 2 only; other modes keep the launch), 0 = separate aggregate launch (default)
     int precision = AG_PREC_B3; // env AG_PRECISION=f32|bf16x3|fast / ag_set_option("precision", 0|1|2)
-    int eterm_half = 1;         // precision mode 2 ("fast"): bf16x3 MFMA + fp16 Eterm table
+    int eterm_half = 1;         // precision mode 2 ("fast"): 16-bit (q16) Eterm table, fp16 edge stack
     int max_blocks = 512;       // persistent grid: 2 workgroups per CU
-    int edge_products = 2;      // precision mode 2: edge stack on two fp16 products per k16-step (fp16 activations x split-fp16 weights);
+    int edge_products = 2;      // precision mode 2: 2 = fp16 edge stack (split-fp16 weights x fp16 activations + e5m2 residual bytes: PrecH3),
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
     int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
-    int edge_rows = 32;         // split-bf16 edge encoder: 32 edges per wave, 2 workgroups per CU (default); 64 = two row blocks per
-                                // wave, one 512-register workgroup per CU (env AG_EDGE_ROWS / "edge_rows"; measured equal solo, -3.5 % in the 2-stream rollout)
     int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
                                 // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
-    int agg_stream = 0;         // experiment builds only (-DAG_EXPERIMENTS, csrc/experiments/): 1 = LDS-DMA streamed segment reduce (measured slower)
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -173,7 +170,7 @@ struct ag_model {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
     size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
     unsigned long long *edge_counter = nullptr;
-    int *status = nullptr;      // device word, sticky: bit 0 = non-finite message sum (fp16 Eterm overflow or non-finite inputs)
+    int *status = nullptr;      // device word, sticky: bit 0 = a forward left the range of its arithmetic (fp16 activation overflow, non-finite values)
 };
 
 namespace {
@@ -209,17 +206,10 @@ int pack_and_upload(ag_model *m, const float *const *t)
         pack_layer(s, b3, t[W_D2], F, 0, F, 3, t[B_D2], 1);
     }
     const size_t off_h2 = s.size();                                        // edge_encode stream, split-fp16
-    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], de - 3);      // + residual columns for the position difference, inputs 14..16 (AG_EDGE_LO_FEAT0)
+    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], 2 * m->cfg.attr_dim + 1);      // + residual columns for the 12 state differences, inputs 5..16 (AG_EDGE_LO_FEAT0)
     pack_layer(s, 2, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
     pack_layer(s, 2, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
     pack_layer(s, 2, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
-#ifdef AG_EXPERIMENTS
-    const size_t off_h6 = s.size();                                        // edge_encode stream, fp16 hi + block-scaled fp6 lo (edge_products 1: experiments/ag_mlp_h6.inc)
-    pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], de - 3);
-    pack_layer(s, 3, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
-    pack_layer(s, 3, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
-    pack_layer(s, 3, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
-#endif
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
@@ -247,30 +237,6 @@ int pack_and_upload(ag_model *m, const float *const *t)
     m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
     m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
     m->w.edge_encode_h2 = reinterpret_cast<const float4 *>(m->dev + off_h2);
-#ifdef AG_EXPERIMENTS
-    m->w.edge_encode_h6 = reinterpret_cast<const float4 *>(m->dev + off_h6);
-    {   // fp6 part of the three wide layers: from the fp32 tensors, on the device (its conversion instruction defines the operand layout)
-        float *tmp = nullptr;
-        const size_t nW = (size_t)F * F, nRP = (size_t)F * 3 * F;
-        AG_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), (2 * nW + nRP + 3 * F) * sizeof(float)));
-        float *dW1 = tmp, *dW2 = tmp + nW, *dRP = tmp + 2 * nW, *dB = dRP + nRP;
-        hipError_t e = hipMemcpy(dW1, t[W_RE1], nW * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dW2, t[W_RE2], nW * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dRP, t[W_RP], nRP * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dB, t[B_RE1], F * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dB + F, t[B_RE2], F * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dB + 2 * F, t[B_RP], F * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            float *h6 = m->dev + off_h6;
-            ag_launch_pack_lo6(dW1, F, 0, F, F, dB, h6 + (size_t)1 * AG_CHUNK_FLOATS, nullptr);
-            ag_launch_pack_lo6(dW2, F, 0, F, F, dB + F, h6 + (size_t)(1 + AG_NT) * AG_CHUNK_FLOATS, nullptr);
-            ag_launch_pack_lo6(dRP, 3 * F, 0, F, F, dB + 2 * F, h6 + (size_t)(1 + 2 * AG_NT) * AG_CHUNK_FLOATS, nullptr);
-            e = hipDeviceSynchronize();
-        }
-        (void)hipFree(tmp);
-        if (e != hipSuccess) return fail(AG_ERR_HIP, "packing the fp6 weight images failed: %s", hipGetErrorString(e));
-    }
-#endif
     return AG_OK;
 }
 
@@ -359,11 +325,9 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
     a.eterm_half = m->eterm_half;
     a.fuse_agg = (m->fuse_agg == 2 && !(a.precision == AG_PREC_B3 && a.eterm_half)) ? 0 : m->fuse_agg;   // mode 2 of the option needs the fp16 table
     a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
-    a.edge_rows = m->edge_rows;
-    a.edge_products = (m->edge_rows == 32 && m->h2_ok) ? m->edge_products : 3;      // the experimental edge kernels are split-bf16 only
+    a.edge_products = m->h2_ok ? m->edge_products : 3;      // a checkpoint with edge-stack weights beyond fp16's range keeps the split-bf16 edge stack
     a.edge_ws = m->edge_ws;
-    a.agg_stream = m->agg_stream;
-    a.dedup = m->node_dedup && a.fuse_agg != 1 && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&    // (the row-per-lane experiment reads Hr directly)
+    a.dedup = m->node_dedup && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&
               (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
     a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
@@ -441,27 +405,16 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     ag_model *m = new ag_model();
     m->cfg = *cfg;
     if (const char *v = getenv("AG_FUSE_AGG")) m->fuse_agg = atoi(v);
-#ifndef AG_EXPERIMENTS
     if (m->fuse_agg != 0 && m->fuse_agg != 2) m->fuse_agg = 0;
-#endif
     if (const char *v = getenv("AG_PRECISION")) {
         const int mode = (!strcmp(v, "f32") || !strcmp(v, "0")) ? 0 : (!strcmp(v, "bf16x3") || !strcmp(v, "1")) ? 1 : 2;
         m->precision = mode ? AG_PREC_B3 : AG_PREC_F32;
         m->eterm_half = mode == 2;
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
-#ifdef AG_EXPERIMENTS
-    if (const char *v = getenv("AG_EDGE_ROWS")) m->edge_rows = atoi(v);
-#endif
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
-#ifdef AG_EXPERIMENTS
-    if (const char *v = getenv("AG_EDGE_PRODUCTS")) if (atoi(v) == 1) m->edge_products = 1;
-#endif
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
-#ifdef AG_EXPERIMENTS
-    if (const char *v = getenv("AG_AGG_STREAM")) m->agg_stream = atoi(v) != 0;
-#endif
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
     {
         int dev = 0;
@@ -689,33 +642,17 @@ int ag_set_option(ag_model *m, const char *name, int value)
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
     if (!strcmp(name, "rollout_streams")) m->split = value;
     else if (!strcmp(name, "fuse_aggregate")) {
-#ifndef AG_EXPERIMENTS
-        if (value != 0 && value != 2) return fail(AG_ERR_ARG, "ag_set_option: fuse_aggregate %d is an experiment (build with -DAG_EXPERIMENTS); the product has 0 and 2", value);
-#endif
+        if (value != 0 && value != 2) return fail(AG_ERR_ARG, "ag_set_option: fuse_aggregate takes 0 (separate launch) or 2 (reduce inside node_update), not %d", value);
         m->fuse_agg = value;
     }
     else if (!strcmp(name, "precision")) { m->precision = value ? AG_PREC_B3 : AG_PREC_F32; m->eterm_half = value == 2; }
     else if (!strcmp(name, "max_blocks")) m->max_blocks = value;
     else if (!strcmp(name, "edge_products")) {
-#ifndef AG_EXPERIMENTS
-        if (value == 1) return fail(AG_ERR_ARG, "edge_products 1 (block-scaled fp6 correction product) is compiled only into -DAG_EXPERIMENTS builds");
-#endif
-        m->edge_products = value == 3 ? 3 : (value == 1 ? 1 : 2);
+        if (value != 2 && value != 3) return fail(AG_ERR_ARG, "ag_set_option: edge_products takes 2 (fp16 edge stack, default) or 3 (split-bf16), not %d", value);
+        m->edge_products = value;
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
-    else if (!strcmp(name, "aggregate_stream")) {
-#ifndef AG_EXPERIMENTS
-        if (value != 0) return fail(AG_ERR_ARG, "ag_set_option: aggregate_stream %d is an experiment (build with -DAG_EXPERIMENTS, csrc/experiments/)", value);
-#endif
-        m->agg_stream = value != 0;
-    }
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (!strcmp(name, "edge_rows")) {
-#ifndef AG_EXPERIMENTS
-        if (value != 32) return fail(AG_ERR_ARG, "ag_set_option: edge_rows %d is an experiment (build with -DAG_EXPERIMENTS); the product runs 32 rows per wave", value);
-#endif
-        m->edge_rows = (value == 64 || value == 33 || value == 34) ? value : 32;
-    }   // 33: 32 rows/wave on the edge_encode_nb pipeline (experiment)
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }

@@ -48,7 +48,6 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *node_encode_b3, *edge_encode_b3, *node_mid_b3, *node_last_b3;
     // the edge stream as split-fp16 fragment images (same layout as the bf16 ones; precision mode 2, two-product edge stack)
     const float4 *edge_encode_h2;
-    const float4 *edge_encode_h6;   // the same stream for PrecH6: W_hi fp16 fragments + block-scaled fp6 W_lo per chunk (edge_products 1)
 };
 
 struct AgFwdArgs {
@@ -70,14 +69,13 @@ struct AgFwdArgs {
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
     float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
     int precision;     // AG_PREC_F32 (exact fp32 MFMA) or AG_PREC_B3 (hi/lo bf16 split, 3 MFMAs per product)
-    int eterm_half;    // 1: the Eterm table is fp16 in accumulator order (precision mode 2)
+    int eterm_half;    // 1: the Eterm table is 16-bit block-scaled fixed point in accumulator order (q16, precision mode 2)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
     int max_blocks;    // persistent grid size = resident workgroups (2 per CU)
     float *edge_node_tab;  // (rows_pad, 16): per-node inputs of the edge features [attr0, attr1, group0, 0, v0(3), v1(3), v2(3), x_cur(3)] (weight-stationary edge encoder)
     int *tile_ctr;     // zeroed int: row-tile claim counter of this forward's edge_encode launch (NULL: static grid stride)
-    int *status;       // sticky device word of the model: bit 0 = a non-finite message sum was produced, bit 1 = a precision-mode-2 forward
-                       // predicted a motion component beyond AG_FAST_ENVELOPE (ag_model_status)
-    int edge_products; // precision mode 2 only: 2 = fp16 activations x split-fp16 weights in the edge stack (default), 3 = split-bf16 like mode 1
+    int *status;       // sticky device word of the model: bit 0 = a forward left the range of its arithmetic (ag_model_status)
+    int edge_products; // precision mode 2 only: 2 = fp16 edge stack with residual bytes (PrecH3, default), 3 = split-bf16 like mode 1
     int ws_blocks;     // workgroups of the weight-stationary edge encoder for this launch
     int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
     // ---- node-encoder de-duplication.  The node encoder sees [attrs | phys | action] only (positions do not enter:
@@ -96,36 +94,48 @@ struct AgFwdArgs {
     const int32_t *hr_row;           // segment reduce: row of Hr to read for node g (NULL: g) — node_row in round 0
     const float *pn_rows;            // node_update: Pn from compact rows pn_rows[node_row[g]] (NULL: packed table pn)
     const float *h_rows;             // node_update, round 0: residual h from compact rows (NULL: packed table h)
-    int agg_stream;    // -DAG_EXPERIMENTS builds only: 1 = streamed segment reduce (experiments/ag_aggregate_stream.inc, measured slower); the product always runs aggregate_half_kernel
-    int edge_rows;     // split-bf16 edge encoder: 32 = one row block per wave, two workgroups per CU (default); 64 = two row blocks
-                       // per wave, one 512-register workgroup per CU; 33 = 32 rows per wave on that pipeline (edge_encode_nb_kernel)
 };
 #define AG_TILE_CTRS 4
-// Precision mode 2 ("fast") deviates from the fp32 forward by about 5e-4 of the largest predicted motion (fp16 activations in the edge stack and the
-// fp16 per-edge table; tools/fuzz_parity.py: <= 7.6e-4 x max|motion| over 1 100 random graphs, worst on weights trained by the reference's train()),
-// i.e. it stays inside the 1e-4 gate while per-step motions stay below ~0.13.  A mode-2 forward that predicts a larger component raises status
-// bit 1 (AG_STATUS_FAST_ENVELOPE) instead of passing a possibly-outside-the-gate result on silently.
-#define AG_FAST_ENVELOPE 0.125f
 #define AG_DEDUP_REPS 8            // distinct node-encoder input rows shared within a sample (more than that: private rows)
 
-// ---- segment reduce of ONE node with the fp16 per-edge table (precision mode 2), shared by aggregate_half_kernel
-//      (ag_aggregate.hip) and the reduce fused into node_update (ag_mlp.hip) ----------------------------------------------
-// A row of Eterm is 160 halves = 20 x 16 B in accumulator order; lane c (0..19) of a node's group owns half-positions
-// [8c, 8c+8) = features f0 + {0..3} and f0 + 8 + {0..3}, f0 = ag_half_lane_feature(c).
+// ---- the per-edge table of precision mode 2: "q16", block-scaled 16-bit fixed point --------------------------------------------
+// A row of Eterm is 320 bytes = [5 out-tiles t][2 lane halves h][16 values] in accumulator order (feature 32t + 8q + 4h + p at 16-bit
+// index 32t + 16h + 4q + p: a lane of the producing MFMA kernel writes 32 contiguous bytes per tile).  The 32 values of one out-tile
+// share a power-of-two scale: with m = max |v| over the tile and eb = the biased fp32 exponent of m (2^(eb-127) <= m < 2^(eb-126)),
+//     stored  q = round_to_nearest_even(v * 2^(126-eb) * 32767)   (v_cvt_pknorm_i16_f32),     value = q * 2^(eb-126) / 32767,
+// i.e. an absolute error <= 2^(eb-142) ~ m / 46 000 for EVERY value of the tile (fp16, the r01-r03 format, rounds each value to 2^-12 of
+// ITSELF: the same 16 bits measured 7 x further from the exact forward, tools/scheme_err.py).  eb is clamped to [AG_Q16_EB_MIN, 252].
+// The five exponent bytes live in the row's own padding (features 150..159 never exist: 20 bytes): bytes 280 + t (t < 4) and 284 (t = 4)
+// from the h = 0 lanes, and once more at 316 + t / 312 from the h = 1 lanes, so that BOTH 16-byte segments that hold padding carry the
+// byte a consumer lane needs in their THIRD dword: segment 17 (bytes 272..287) tiles 0..3, segment 19 (bytes 304..319) tile 4.
+#define AG_Q16_EB_MIN 20
+#define AG_Q16_EB_MAX 252
+__device__ __forceinline__ int ag_q16_exp_byte_offset(int t, int h) { return h ? (t == 4 ? 312 : 316 + t) : (t == 4 ? 284 : 280 + t); }
+__device__ __forceinline__ float ag_q16_scale(int eb) { return ldexpf(1.0f / 32767.0f, eb - 126); }
+
+// ---- segment reduce of ONE node over the q16 table, shared by aggregate_half_kernel (ag_aggregate.hip) and the reduce fused into
+//      node_update (ag_mlp.hip) ------------------------------------------------------------------------------------------------------
+// Twenty adjacent lanes of ONE wave own a node (three nodes per wave, lanes 60..63 idle); lane c (0..19) owns the 16-byte segment c of
+// every edge row = features f0 + {0..3} and f0 + 8 + {0..3}, f0 = ag_half_lane_feature(c), of out-tile c >> 2.  The tile's exponent byte
+// arrives by ONE ds_bpermute per edge from the third dword of lane 17's (tiles 0..3) or lane 19's (tile 4) own load — no extra memory
+// instruction (the reduce is bound by the texture pipe).
 // A node has ~10 edges and every edge costs a dependent index -> row round trip, so FOUR edges are kept in flight per lane and
-// the sender indices of the next four are fetched one iteration ahead (the adds still run in ascending edge order:
-// bit-identical to a sequential loop).  Measured 0.303 -> 0.292 ms vs two in flight; nontemporal Eterm loads: worse.
+// the sender indices of the next four are fetched one iteration ahead (the adds still run in ascending edge order: bit-identical to a
+// sequential loop).
 #define AG_AGG_IN_FLIGHT 4
+#define AG_AGG_GROUP 20             // lanes per node
+#define AG_AGG_NODES_PER_WAVE 3
 __device__ __forceinline__ int ag_half_lane_feature(int c) { return 32 * (c >> 2) + 8 * (2 * (c & 1)) + 4 * ((c >> 1) & 1); }
 
 template <int kInFlight = AG_AGG_IN_FLIGHT>
-__device__ __forceinline__ void ag_reduce_node_half(const AgFwdArgs &a, int g, int c, float4 &acc0, float4 &acc1)
+__device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
 {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int f0 = ag_half_lane_feature(c);
     const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
-    const _Float16 *et = reinterpret_cast<const _Float16 *>(a.eterm) + 8 * c;
+    const int4 *et = reinterpret_cast<const int4 *>(a.eterm) + c;          // segment c of row e: et[e * 20]
     const float *hs = a.hs + f0;
+    const int exp_src = (group_lane0 + (c < 16 ? 17 : 19)) << 2;           // ds_bpermute byte address of the lane that loaded the exponent bytes
+    const int exp_shift = c < 16 ? 8 * (c >> 2) : 0;
     int s[kInFlight];
 #pragma unroll
     for (int i = 0; i < kInFlight; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
@@ -134,39 +144,44 @@ __device__ __forceinline__ void ag_reduce_node_half(const AgFwdArgs &a, int g, i
     const float4 hr1 = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + f0 + 8);
     acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
     acc1 = acc0;
-    for (int e = e0; e < e1; e += kInFlight) {
+    for (int e = e0; e < e1; e += kInFlight) {       // e0, e1 and with them every branch below are uniform over the node's 20 lanes
         int sn[kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) sn[i] = e + kInFlight + i < e1 ? a.edge_send[e + kInFlight + i] : -1;
-        h8 t[kInFlight];
+        int4 t[kInFlight];
         float4 u0[kInFlight], u1[kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                t[i] = *reinterpret_cast<const h8 *>(et + (size_t)(e + i) * AG_FP);
+                t[i] = et[(size_t)(e + i) * (AG_FP / 8)];
                 u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
                 u1[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP + 8);
             }
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                acc0.x += fmaxf(((float)t[i][0] + hr0.x) + u0[i].x, 0.f); acc0.y += fmaxf(((float)t[i][1] + hr0.y) + u0[i].y, 0.f);
-                acc0.z += fmaxf(((float)t[i][2] + hr0.z) + u0[i].z, 0.f); acc0.w += fmaxf(((float)t[i][3] + hr0.w) + u0[i].w, 0.f);
-                acc1.x += fmaxf(((float)t[i][4] + hr1.x) + u1[i].x, 0.f); acc1.y += fmaxf(((float)t[i][5] + hr1.y) + u1[i].y, 0.f);
-                acc1.z += fmaxf(((float)t[i][6] + hr1.z) + u1[i].z, 0.f); acc1.w += fmaxf(((float)t[i][7] + hr1.w) + u1[i].w, 0.f);
+                const int eb = (__builtin_amdgcn_ds_bpermute(exp_src, t[i].z) >> exp_shift) & 0xff;
+                const float sc = ag_q16_scale(eb);
+                const float q0 = (float)(short)(t[i].x & 0xffff), q1 = (float)(t[i].x >> 16), q2 = (float)(short)(t[i].y & 0xffff), q3 = (float)(t[i].y >> 16);
+                const float q4 = (float)(short)(t[i].z & 0xffff), q5 = (float)(t[i].z >> 16), q6 = (float)(short)(t[i].w & 0xffff), q7 = (float)(t[i].w >> 16);
+                acc0.x += fmaxf(fmaf(q0, sc, hr0.x) + u0[i].x, 0.f); acc0.y += fmaxf(fmaf(q1, sc, hr0.y) + u0[i].y, 0.f);
+                acc0.z += fmaxf(fmaf(q2, sc, hr0.z) + u0[i].z, 0.f); acc0.w += fmaxf(fmaf(q3, sc, hr0.w) + u0[i].w, 0.f);
+                acc1.x += fmaxf(fmaf(q4, sc, hr1.x) + u1[i].x, 0.f); acc1.y += fmaxf(fmaf(q5, sc, hr1.y) + u1[i].y, 0.f);
+                acc1.z += fmaxf(fmaf(q6, sc, hr1.z) + u1[i].z, 0.f); acc1.w += fmaxf(fmaf(q7, sc, hr1.w) + u1[i].w, 0.f);
             }
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) s[i] = sn[i];
     }
-    // An fp16 Eterm entry beyond +-65504 was stored as inf (edge_encode, precision mode 2) and surfaces here as a non-finite sum:
-    // raise the model's sticky status bit (read by ag_model_status) instead of passing it on silently — the decoder's clamp
-    // (model.py:309) would otherwise turn it into a plausible +-100 motion.
+    // the padding positions (features 150..159) decoded the exponent bytes: they are not features
+    if (c == 17) acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c == 19) { acc0.z = 0.f; acc0.w = 0.f; acc1 = make_float4(0.f, 0.f, 0.f, 0.f); }
+    // non-finite node terms (Hr / Hs) surface here as a non-finite sum: raise the model's sticky status bit (ag_model_status) instead of
+    // passing it on silently — the decoder's clamp (model.py:309) would otherwise turn it into a plausible +-100 motion
     if (a.status && !isfinite(((acc0.x + acc0.y) + (acc0.z + acc0.w)) + ((acc1.x + acc1.y) + (acc1.z + acc1.w)))) atomicOr(a.status, 1);
 }
 
 // kernel launchers (one translation unit each)
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
-void ag_launch_pack_lo6(const float *W, int ld, int col0, int K, int n_out, const float *bias, float *chunks, hipStream_t s);
 void ag_launch_send_remap(const AgFwdArgs &a, hipStream_t s);
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s);

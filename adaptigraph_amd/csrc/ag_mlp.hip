@@ -4,7 +4,7 @@
 //         lo*hi + hi*lo + hi*hi accumulated in fp32 ("bf16x3"): ~2^-17 relative operand error, measured
 //         1e-6..6e-6 max-abs on the reference forwards (gate 1e-4), 16/3 = 5.3x the fp32 MFMA rate.
 //   H2  : v_mfma_f32_32x32x16_f16  — EDGE stack of precision mode 2 only: activations rounded to one fp16, weights split
-//         hi + lo (two fp16), lo*x + hi*x ("fp16x2", struct PrecH2); streaming kernel edge_encode_kernel<PrecH2> and the
+//         hi + lo (two fp16), lo*x + hi*x ("fp16x2", struct PrecH3); streaming kernel edge_encode_kernel<PrecH3> and the
 //         weight-stationary edge_encode_ws_kernel (the default: weights in registers, activations through LDS).
 //
 // Replaces the reference's Encoder / Propagator / ParticlePredictor stacks
@@ -31,10 +31,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-#ifndef AG_ABL
-#define AG_ABL 0   // timing-only ablation bits for A/B builds (tools/ab_build.sh); 0 in the shipped library
-#endif
 
 namespace {
 
@@ -88,21 +84,8 @@ __device__ __forceinline__ unsigned lds_addr_of(const void *p)
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-#ifndef AG_E64_PIN
-#define AG_E64_PIN 1     // sched_barrier(0) after every epilogue-unit slot of the two-block layers (0: leave placement to the compiler:
-                         // measured 0.901 vs 0.868 ms; an explicit sched_group_barrier interleave of 12 x (1 MFMA, 4 VALU) per slot: 0.905)
-#endif
-#ifndef AG_H2_WG_PER_CU
-#define AG_H2_WG_PER_CU 3    // edge_encode_kernel<PrecH2>: <= 168 registers, 40 KB LDS per workgroup
-#endif
-#ifndef AG_TRACE
-#define AG_TRACE 0      // debug builds only (tools/trace_tiles.py): s_memtime stamps of one wave's tile phases
-#endif
-#if AG_TRACE
-__device__ unsigned long long ag_trace_buf[4 * 512];
-#define AG_STAMP(P) do { if ((P).tr >= 0 && (P).tr < 512) { ag_trace_buf[(P).trb + (P).tr] = __builtin_readcyclecounter(); (P).tr++; } } while (0)
-#else
-#define AG_STAMP(P) do { } while (0)
+#ifndef AG_H3_WG_PER_CU
+#define AG_H3_WG_PER_CU 2    // edge_encode_kernel<PrecH3>: two activation images (fp16 + expanded residual) per Act, 40 KB LDS per workgroup
 #endif
 
 struct ChunkPipe {
@@ -111,9 +94,6 @@ struct ChunkPipe {
     int fetch;         // next stream chunk to fetch (wraps at total)
     int buf;           // LDS buffer holding the current chunk (0/1)
     float *lds;        // 2 * AG_CHUNK_FLOATS
-#if AG_TRACE
-    int tr = -1, trb = 0;
-#endif
 };
 
 // Asynchronous global -> LDS copy of the next weight chunk (global_load_lds_dwordx4: LDS-DMA, no VGPR staging,
@@ -164,11 +144,8 @@ __device__ __forceinline__ void pipe_start(ChunkPipe &P)
 
 // ---- per-tile epilogues (run right after a 32-feature out-tile is finished, so its stores overlap the next
 //      tile's MFMAs instead of piling up behind the layer) -------------------------------------------------
-// Each epilogue can also be applied in two halves: half s covers accumulator registers 8s..8s+7 of the out-tile (the
-// unit in which the two-block kernels schedule their epilogue work between k16-steps).
 struct NoEpi {
     __device__ __forceinline__ void operator()(int, const f32x16 &) const {}
-    __device__ __forceinline__ void half(int, int, const f32x16 &) const {}
 };
 // Epilogue stores are unconditional: a row past the valid range writes into the table's padding rows (every table is
 // allocated in whole row tiles), which keeps the epilogue branch-free.
@@ -180,42 +157,66 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
-    __device__ __forceinline__ void half(int ti, int s, const f32x16 &v) const
-    {
-#pragma unroll
-        for (int q = 2 * s; q < 2 * s + 2; ++q)
-            *reinterpret_cast<float4 *>(row + 32 * ti + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    }
 };
-struct RowStoreHalfEpi {    // Eterm as fp16 (precision mode 2): row = [5 tiles][2 halves h][16 values in accumulator order],
-    _Float16 *row;          // i.e. feature 32t + 8q + 4h + p sits at half index 32t + 16h + 4q + p; row = table + e*160 + 16h
-    int *status = nullptr;  // model status word: bit 0 is raised when a value does not fit fp16 (|v| > 65504, inf or NaN — which the
-                            // reduce's relu would otherwise turn into a silent 0): one v_cmp per value, the atomic only on overflow
-    __device__ __forceinline__ void check(const f32x16 &v, int r0, int n) const
-    {
-        bool bad = false;
-#pragma unroll
-        for (int r = r0; r < r0 + n; ++r) bad |= !(fabsf(v[r]) <= 65504.0f);
-        if (bad && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
-    }
+
+// ---- q16: the 16-bit per-edge table of precision mode 2 (format: ag_common.h).  The pieces below are shared by the streaming kernels'
+//      epilogue (RowStoreQ16Epi) and the weight-stationary kernel's micro-chores, so both write the same bits. ------------------------------
+// largest |v| of two values against a running maximum, on the BIT PATTERNS (|x| orders like an unsigned integer, and inf / NaN sort above
+// every finite value, so a non-finite accumulator ends up in the block exponent instead of vanishing in a float maximum)
+__device__ __forceinline__ unsigned q16_max2(unsigned m, float a, float b)
+{
+    const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu;
+    return max(m, max(ua, ub));
+}
+// block exponent of an out-tile from the lane's own maximum: the other half of the tile's rows sits in lane j + 32 (v_permlane32_swap)
+__device__ __forceinline__ int q16_tile_exp(unsigned m, bool &nonfinite)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    m = max(sw.x, sw.y);
+    nonfinite = m >= 0x7f000000u;               // >= 2^127, inf or NaN: cannot be scaled into [-1, 1)
+    const int eb = (int)(m >> 23);
+    return eb < AG_Q16_EB_MIN ? AG_Q16_EB_MIN : (eb > AG_Q16_EB_MAX ? AG_Q16_EB_MAX : eb);
+}
+__device__ __forceinline__ float q16_inv_scale(int eb) { return __uint_as_float((unsigned)(253 - eb) << 23); }      // 2^(126 - eb)
+__device__ __forceinline__ unsigned q16_pack(float a, float b, float inv)          // two values -> packed snorm16 (round to nearest even)
+{
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, (s16x2)__builtin_amdgcn_cvt_pknorm_i16(a * inv, b * inv));
+}
+// stores of one out-tile of lane (j, h): `row` = table + e * 320 bytes; the lane's 32 bytes start at 64 ti + 32 h.  In tile 4 the last eight
+// bytes of the lane's chunk are padding that holds exponent bytes written by OTHER lanes / waves: they are not touched.
+__device__ __forceinline__ void q16_store_half(unsigned char *row, int ti, int h, int s, const unsigned (&w)[4])
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned char *p = row + 64 * ti + 32 * h + 16 * s;
+    if (ti == 4 && s == 1) *reinterpret_cast<u32x2 *>(p) = u32x2{w[0], w[1]};
+    else *reinterpret_cast<u32x4 *>(p) = u32x4{w[0], w[1], w[2], w[3]};
+}
+__device__ __forceinline__ void q16_store_exp(unsigned char *row, int ti, int h, int eb) { row[ag_q16_exp_byte_offset(ti, h)] = (unsigned char)eb; }
+
+struct RowStoreQ16Epi {     // Eterm as q16 (precision mode 2)
+    unsigned char *row;     // table + e * 320
+    int h;
+    int *status = nullptr;  // model status word: bit 0 is raised when a tile holds a non-finite value (or one beyond 2^127)
     __device__ __forceinline__ void operator()(int ti, const f32x16 &v) const
     {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        h8 a, b;
+        unsigned m = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { a[r] = (_Float16)v[r]; b[r] = (_Float16)v[8 + r]; }
-        *reinterpret_cast<h8 *>(row + 32 * ti) = a;
-        *reinterpret_cast<h8 *>(row + 32 * ti + 8) = b;
-        check(v, 0, 16);
-    }
-    __device__ __forceinline__ void half(int ti, int s, const f32x16 &v) const
-    {
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        h8 a;
+        for (int r = 0; r < 16; r += 2) m = q16_max2(m, v[r], v[r + 1]);
+        bool bad;
+        const int eb = q16_tile_exp(m, bad);
+        const float inv = q16_inv_scale(eb);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = (_Float16)v[8 * s + r];
-        *reinterpret_cast<h8 *>(row + 32 * ti + 8 * s) = a;
-        check(v, 8 * s, 8);
+        for (int s = 0; s < 2; ++s) {
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = q16_pack(v[8 * s + 2 * k], v[8 * s + 2 * k + 1], inv);
+            q16_store_half(row, ti, h, s, w);
+        }
+        q16_store_exp(row, ti, h, eb);
+        if (bad && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
     }
 };
 struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_lane = table + block*5120 + h*128 + j*4
@@ -350,9 +351,6 @@ struct PrecF32 {
 };
 
 
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_mlp_ring4.inc"
-#endif
 
 struct PrecB3 {
     // step u = 2t + s covers features [16u, 16u+16): lane (j,h) slot e holds feature 16u + 8(e>>2) + 4h + (e&3),
@@ -377,7 +375,7 @@ struct PrecB3 {
             const unsigned hp = cvt_pk_bf16(x0, x1);
             const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
             H[w] = hp;
-            L[w] = (AG_ABL & 1) ? hp : cvt_pk_bf16(x0 - h0, x1 - h1);
+            L[w] = cvt_pk_bf16(x0 - h0, x1 - h1);
         }
         a.hi[2 * ti + s] = __builtin_bit_cast(bf16x8, H);
         a.lo[2 * ti + s] = __builtin_bit_cast(bf16x8, L);
@@ -397,17 +395,15 @@ struct PrecB3 {
         auto finish = [&](int ti, f32x16 &v) {
             if (RELU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = (AG_ABL & 32) ? v[r] : relu1(v[r]);
+                for (int r = 0; r < 16; ++r) v[r] = relu1(v[r]);
             }
-            if (!(AG_ABL & 8) || v[0] == 1234.5678f) epi(ti, v);   // (ablation keeps the value live: no DCE)
+            epi(ti, v);
             sink(ti, v);
         };
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
-            AG_STAMP(P);
-            if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
-            AG_STAMP(P);
+            pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
             static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
@@ -416,7 +412,6 @@ struct PrecB3 {
                 lds_read16<(2 * u + 1) * 1024>(wq[u][1], la);
             });
             if (ti > 0) finish(ti - 1, prev);
-            AG_STAMP(P);
             static_for<0, NU>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 if constexpr (u + PF < NU) {
@@ -436,11 +431,8 @@ struct PrecB3 {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
             });
             prev = acc;
-            AG_STAMP(P);
-            if (!(AG_ABL & 16)) pipe_wait();
-            AG_STAMP(P);
-            if (!(AG_ABL & 2)) __syncthreads();
-            AG_STAMP(P);
+            pipe_wait();
+            __syncthreads();
             P.buf ^= 1;
         }
         finish(NT - 1, prev);
@@ -492,62 +484,85 @@ struct PrecB3 {
         P.buf ^= 1;
     }
 
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_mlp_b3_nb_layers.inc"      // layer_nb / layer_first_nb (NB row blocks per wave)
-#endif
 };
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// H2 ("fp16x2"): TWO products per k16-step instead of three, for the EDGE stack of precision mode 2 only.
-//   activation x -> ONE fp16 (RNE, 11 significant bits);  weight W = hi + lo, two fp16 (lo is mostly subnormal: the fp16 MFMA
-//   honours subnormal inputs on gfx950 — tools/ubench/mfma_f16_denorm.hip — so W carries >= 19 bits, absolute error <= 2^-25);
-//   acc += lo*x; acc += hi*x on v_mfma_f32_32x32x16_f16, fp32 accumulate.
-// Why this is enough HERE and nowhere else: a rounding error of 2^-12 per activation is random and averages out over the
-// 150-term dot products and over the edges summed into a node; emulated in float64 on the reference forwards it costs
-// 1.6e-6 .. 6.4e-6 (tools/two_product_err.py; the gate is 1e-4), less than the fp16 Eterm table mode 2 already uses.  The same
-// rounding on the NODE-level layers costs 2.2e-4 (node states feed three rounds of 20-neighbour sums), and rounding the
-// weights instead of the activations costs 3x more — so node kernels, and modes 0/1 everywhere, keep their arithmetic.
-// What it buys: the edge encoder is power-limited (pure bf16 MFMA chains on random data sustain 1.78 PF at
-// 1 300 W, fp16 chains 1.63 PF), so the only lever is fewer MFMAs: 320 instead of 480 per 32 edges, one convert instead of a
-// 6-op hi/lo split per value pair, and half the operand registers (three workgroups per CU instead of two).
-// RANGE: a hidden activation beyond +-65504 converts to +inf.  That is reported only when it survives to the per-edge table as a
-// non-finite value (ag_model_status): inf x negative weight = -inf, and the one-op ReLU (an integer max) turns -inf and
-// sign-bit NaNs into 0, so an overflow CAN be swallowed by the next hidden layer.  The status word is therefore a detector of
-// Eterm overflow, not a guarantee for the hidden activations: for checkpoints with an unknown activation range use precision 1
+// H3 ("fp16 + e5m2 residual"): the arithmetic of the EDGE stack in precision mode 2.  Three fp16 MFMAs per k16-step:
+//   weight W = hi + lo, two fp16 (lo is mostly subnormal: the fp16 MFMA honours subnormal inputs on gfx950 —
+//   tools/ubench/mfma_f16_denorm.hip — so W carries >= 19 bits, absolute error <= 2^-25);
+//   activation x = x16 + r8:  x16 = fp16(x) (RNE, 11 significant bits),  r8 = e5m2(x - x16) (RNE, 3 significant bits: ONE byte,
+//   the top byte of the fp16 pattern of the residual, expanded to fp16 by a byte permute where it is consumed);
+//   acc += lo*x16; acc += hi*x16; acc += hi*r8   on v_mfma_f32_32x32x16_f16, fp32 accumulate.
+// History: r02-r03 ran the first two products only.  On weights trained by the reference the fp16 rounding of the
+// ACTIVATIONS (2^-12 relative, every layer of the stack contributing alike) then costs 2-5e-5 of the 1e-4 gate and grows with the
+// predicted motion (1.4e-4 at |motion| 0.2 in tools/fuzz_parity.py).  The residual byte removes 7/8 of it for 5 KB of LDS per layer
+// image instead of the 10 KB a second fp16 image would take (the weight-stationary kernel's LDS is full), at no extra weight registers
+// (the third product re-uses the hi fragments); float64 emulation on the fuzz cases (tools/scheme_err.py): 4.9e-5 -> 5.6e-6 together
+// with the q16 table, the level of the split-bf16 mode.
+// RANGE: a hidden activation beyond +-65504 converts to +inf.  Every epilogue keeps the largest fp16 bit pattern it produced
+// (`bad`, one packed integer maximum per value pair) and raises status bit 0 when it reaches 0x7c00 (inf / NaN): the overflow is
+// reported WHERE it happens, whatever later layers make of it.  For checkpoints with larger activations use precision 1
 // (split-bf16, fp32 range).  Measured head-room: the trained goldens rescaled to 64x larger edge-stack activations
 // (tests/golden/*act64*, tools/gen_trained.py) still match within the mode's tolerance with status 0.
-// FIRST layer of the edge stack: its 17 inputs + bias column use 18 of the 32 K slots of two k16-steps.  Three of the inputs are the current
-// position difference x_r - x_s, of any size (a tool joined to every cloth particle by connect_tools_all sits metres away: |x| ~ 50 rounds to
-// fp16 with an error of 0.01; the velocity differences are 10-100x smaller and so are their rounding errors).  Spare slots 18..20 carry the
-// fp16 rounding residuals of inputs 14..16 against the same weight columns (ag_api.hip pack_first_layer), so the first layer sees those
-// inputs to 2^-22 at no extra MFMA: tools/fuzz_parity.py's worst mode-2 cases were these.
+// FIRST layer of the edge stack: its 17 inputs + bias column use 18 of the 32 K slots of two k16-steps.  Twelve of the inputs are
+// position / velocity differences of any size (a tool joined to every cloth particle by connect_tools_all sits metres away: |x| ~ 50
+// rounds to fp16 with an error of 0.01).  Spare slots 18..29 carry the fp16 rounding residuals of inputs 5..16 against the same weight
+// columns (ag_api.hip pack_first_layer), so the first layer sees them to 2^-22 at no extra MFMA and needs no third product.
 #define AG_EDGE_LO_SLOT0 (AG_EDGE_IN + 1)       // first residual slot
-#define AG_EDGE_LO_FEAT0 (AG_EDGE_IN - 3)       // first input with a residual: cur_r - cur_s (model.py:249-250)
-#define AG_EDGE_LO_COUNT 3
-static_assert(AG_EDGE_LO_SLOT0 == 18 && AG_EDGE_LO_FEAT0 == 14, "edge_encode_ws_kernel builds slots 18..20 by hand");
+#define AG_EDGE_LO_FEAT0 (2 * AG_ATTR + 1)      // first input with a residual: the state differences (model.py:241-253)
+#define AG_EDGE_LO_COUNT (AG_EDGE_IN - AG_EDGE_LO_FEAT0)
+static_assert(AG_EDGE_LO_SLOT0 == 18 && AG_EDGE_LO_FEAT0 == 5 && AG_EDGE_LO_COUNT == 12, "edge_encode_ws_kernel builds slots 18..29 by hand");
 __device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
 
-struct PrecH2 {
-    struct Act { f16x8 v[2 * AG_NT]; };
+typedef unsigned h3_u32x4 __attribute__((ext_vector_type(4)));
+// two (already ReLU'd) fp32 activations -> the packed fp16 pair and their two residual bytes (into the low or high half of R)
+template <bool SIGNED = false>      // SIGNED: the values may be negative (raw first-layer inputs): the range check then ignores the sign bits
+__device__ __forceinline__ unsigned h3_pair(float x0, float x1, int &R, bool hi_word, unsigned &bad)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {x0, x1};
+    const f16x2 hx = __builtin_convertvector(x, f16x2);
+    const unsigned H = __builtin_bit_cast(unsigned, hx);
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    bad = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, bad), __builtin_bit_cast(u16x2, SIGNED ? (H & 0x7fff7fffu) : H)));
+    const float r0 = x0 - (float)hx[0], r1 = x1 - (float)hx[1];
+    R = hi_word ? __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, R, true) : __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, R, false);
+    return H;
+}
+// eight residual bytes (R[0] = elements 0..3, R[1] = 4..7) -> eight fp16: byte b becomes the half-word b << 8 (e5m2 IS the top byte of fp16)
+__device__ __forceinline__ h3_u32x4 h3_expand(int R0, int R1)
+{
+    h3_u32x4 r;
+    r[0] = __builtin_amdgcn_perm((unsigned)R0, (unsigned)R0, 0x010c000cu);
+    r[1] = __builtin_amdgcn_perm((unsigned)R0, (unsigned)R0, 0x030c020cu);
+    r[2] = __builtin_amdgcn_perm((unsigned)R1, (unsigned)R1, 0x010c000cu);
+    r[3] = __builtin_amdgcn_perm((unsigned)R1, (unsigned)R1, 0x030c020cu);
+    return r;
+}
+// status bit 0 when a lane produced an fp16 inf / NaN (bit patterns >= 0x7c00 in either half-word of `bad`)
+__device__ __forceinline__ void h3_report(unsigned bad, int *status)
+{
+    if (((bad + 0x04000400u) & 0x80008000u) && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
+}
+
+struct PrecH3 {
+    struct Act { f16x8 v[2 * AG_NT], r[2 * AG_NT]; unsigned bad = 0; };
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
     {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            u32x4 H;
+            h3_u32x4 H;
+            int R[2] = {0, 0};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f32x2 x = {v[8 * s + 2 * w], v[8 * s + 2 * w + 1]};
-                H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
-            }
+            for (int w = 0; w < 4; ++w) H[w] = h3_pair<true>(v[8 * s + 2 * w], v[8 * s + 2 * w + 1], R[w >> 1], (w & 1) != 0, a.bad);
             a.v[2 * ti + s] = __builtin_bit_cast(f16x8, H);
+            a.r[2 * ti + s] = __builtin_bit_cast(f16x8, h3_expand(R[0], R[1]));
         }
     }
 
-    // same tile loop as PrecB3::layer (weight ring, fragment prefetch, deferred epilogue), two MFMAs per k16-step
+    // same tile loop as PrecB3::layer (weight ring, fragment prefetch, deferred epilogue), three MFMAs per k16-step
     template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
     __device__ __forceinline__ static void layer(ChunkPipe &P, const Act &in, const Init &init, const Epi &epi, Sink &&sink)
     {
@@ -561,13 +576,13 @@ struct PrecH2 {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = relu1(v[r]);
             }
-            if (!(AG_ABL & 8) || v[0] == 1234.5678f) epi(ti, v);   // (ablation keeps the value live: no DCE)
+            epi(ti, v);
             sink(ti, v);
         };
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
-            if (!(AG_ABL & 4)) pipe_dma(P, P.buf ^ 1);
+            pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
             static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
@@ -586,21 +601,23 @@ struct PrecH2 {
                 lds_wait_pair<2 * ahead>(wq[u % (PF + 1)][0], wq[u % (PF + 1)][1]);
                 const f16x8 wh = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][0]), wl = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][1]);
                 f16x8 x = in.v[u];
-                if constexpr (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3)
+                if constexpr (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3); its residual byte is 0 (the feature itself is padding)
                     constexpr int o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
                     if (h == hb) x[e] = (_Float16)1.0f;
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, in.r[u], acc, 0, 0, 0);
             });
             prev = acc;
-            if (!(AG_ABL & 16)) pipe_wait();
-            if (!(AG_ABL & 2)) __syncthreads();
+            pipe_wait();
+            __syncthreads();
             P.buf ^= 1;
         }
         finish(NT - 1, prev);
     }
 
+    // narrow first layer: two products (its inputs carry their own residuals in spare K slots, see above)
     template <int K, class Sink>
     __device__ __forceinline__ static void layer_first(ChunkPipe &P, const Act &in, Sink &&sink)
     {
@@ -676,9 +693,6 @@ __device__ __forceinline__ void load_rowmajor(const float *row, f32x16 (&v)[AG_N
         }
 }
 
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_mlp_aggregate_rows.inc"      // aggregate_rows<HALF>: fuse_aggregate 1
-#endif
 
 #define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS]; __shared__ int s_next_tile[2];
 
@@ -699,7 +713,7 @@ struct TileQueue {
 template <class Prec> __device__ __forceinline__ const float4 *pick(const float4 *f32, const float4 *b3);
 template <> __device__ __forceinline__ const float4 *pick<PrecF32>(const float4 *f32, const float4 *) { return f32; }
 template <> __device__ __forceinline__ const float4 *pick<PrecB3>(const float4 *, const float4 *b3) { return b3; }
-template <> __device__ __forceinline__ const float4 *pick<PrecH2>(const float4 *, const float4 *b3) { return b3; }   // (the caller passes the fp16 image)
+template <> __device__ __forceinline__ const float4 *pick<PrecH3>(const float4 *, const float4 *b3) { return b3; }   // (the caller passes the fp16 image)
 
 // ---------------------------------------------------------------------------------------------
 // Node encoder + pstep-invariant node terms.
@@ -869,14 +883,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
 // The one-hot gathers Rr.bmm / Rs.bmm become indexed reads of the (L2-resident) raw node inputs.
 // ---------------------------------------------------------------------------------------------
 template <class Prec> constexpr int kEdgeWgPerCu = AG_MLP_WG_PER_CU;
-template <> constexpr int kEdgeWgPerCu<PrecH2> = AG_H2_WG_PER_CU;
+template <> constexpr int kEdgeWgPerCu<PrecH3> = AG_H3_WG_PER_CU;
 // weight stream of the edge stack per arithmetic, and whether its first-layer image carries the residual columns (f16_residual)
 template <class Prec> constexpr bool kEdgeResidualSlots = false;
-template <> constexpr bool kEdgeResidualSlots<PrecH2> = true;
-template <class Prec> __device__ __forceinline__ const float4 *edge_stream(const AgWeights &w) { return pick<Prec>(w.edge_encode, std::is_same_v<Prec, PrecH2> ? w.edge_encode_h2 : w.edge_encode_b3); }
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_mlp_h6.inc"      // PrecH6: the second product of PrecH2 on the block-scaled fp6 MFMA (edge_products 1)
-#endif
+template <> constexpr bool kEdgeResidualSlots<PrecH3> = true;
+template <class Prec> __device__ __forceinline__ const float4 *edge_stream(const AgWeights &w) { return pick<Prec>(w.edge_encode, std::is_same_v<Prec, PrecH3> ? w.edge_encode_h2 : w.edge_encode_b3); }
 template <class Prec>
 __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_encode_kernel(AgWeights w, AgFwdArgs a)
 {
@@ -890,25 +901,13 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
     ChunkPipe P{edge_stream<Prec>(w), 16, 0, 0, lds};
     pipe_start(P);
     TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
-#if AG_TRACE
-    int it = -1;
-#endif
 #pragma unroll 1
     while (q.tile < ntiles) {
         const int tile = q.tile;
         q.claim();
-#if AG_TRACE
-        ++it;
-        {   // record the 6th row tile of wave 0 in blocks 0, 1, 256, 257
-            const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 256 ? 2 : blockIdx.x == 257 ? 3 : -1;
-            P.tr = (it == 5 && slot >= 0 && wave == 0) ? 0 : -1;
-            P.trb = (slot < 0 ? 0 : slot) * 512;
-            AG_STAMP(P);
-        }
-#endif
         const int e = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = e < E;
-        const int r = (AG_ABL & 64) ? (e & 1023) : (valid ? a.edge_recv[e] : 0), s = (AG_ABL & 64) ? ((e * 7) & 1023) : (valid ? a.edge_send[e] : 0);
+        const int r = valid ? a.edge_recv[e] : 0, s = valid ? a.edge_send[e] : 0;
         const int b = r / a.N, ri = r - b * a.N, si = s - b * a.N;
 
         float feat[24];
@@ -950,7 +949,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int p = 0; p < 4; ++p) in0[4 * q + p] = h ? feat[8 * q + 4 + p] : feat[8 * q + p];
-        if constexpr (kEdgeResidualSlots<Prec>) {      // fp16 residuals of the position inputs in the spare K slots (see f16_residual)
+        if constexpr (kEdgeResidualSlots<Prec>) {      // fp16 residuals of the state differences in the spare K slots 18..29 (see f16_residual)
 #pragma unroll
             for (int q = 2; q < 4; ++q)
 #pragma unroll
@@ -958,8 +957,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
                     const int k0 = 8 * q + p, k1 = k0 + 4;      // this lane half's slot: k0 (h = 0) or k1 (h = 1)
                     const bool l0 = k0 >= AG_EDGE_LO_SLOT0 && k0 < AG_EDGE_LO_SLOT0 + AG_EDGE_LO_COUNT;
                     const bool l1 = k1 >= AG_EDGE_LO_SLOT0 && k1 < AG_EDGE_LO_SLOT0 + AG_EDGE_LO_COUNT;
-                    const float v0 = l0 ? f16_residual(feat[k0 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k0 < 24 ? feat[k0] : 0.0f);
-                    const float v1 = l1 ? f16_residual(feat[k1 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k1 < 24 ? feat[k1] : 0.0f);
+                    const float v0 = l0 ? f16_residual(feat[k0 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k0 < 18 ? feat[k0] : 0.0f);
+                    const float v1 = l1 ? f16_residual(feat[k1 - AG_EDGE_LO_SLOT0 + AG_EDGE_LO_FEAT0]) : (k1 < 18 ? feat[k1] : 0.0f);
                     in0[4 * q + p] = h ? v1 : v0;
                 }
         }
@@ -970,10 +969,11 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         q.publish();
         dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});
         dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // relation_encode
-        if (a.eterm_half)    // Eterm (fp16 table in precision mode 2)
-            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreHalfEpi{reinterpret_cast<_Float16 *>(a.eterm) + (size_t)e * AG_FP + 16 * h, a.status});
+        if (a.eterm_half)    // Eterm (q16 table in precision mode 2)
+            dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreQ16Epi{reinterpret_cast<unsigned char *>(a.eterm) + (size_t)e * (2 * AG_FP), h, a.status});
         else
             dense_store<Prec, AG_F, false, true>(P, y, ZeroInit{}, RowStoreEpi{a.eterm + (size_t)e * AG_FP + 4 * h});
+        if constexpr (std::is_same_v<Prec, PrecH3>) { h3_report(x.bad, a.status); h3_report(y.bad, a.status); }      // a hidden activation left fp16's range
         q.next();
     }
 }
@@ -1034,48 +1034,48 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 }
 
 // =====================================================================================================================
-// Weight-STATIONARY edge encoder (precision mode 2, two-product fp16 arithmetic of PrecH2; the default there, ag_set_option("edge_stationary", 0) selects the streaming kernel).
+// Weight-STATIONARY edge encoder (precision mode 2, the three-product arithmetic of PrecH3; the default there, ag_set_option("edge_stationary", 0) selects the streaming kernel).
 //
 // The streaming kernels above re-read the whole 320 KB weight image from L2 through LDS for every 128 edges: 2 560 B of
 // L2->LDS traffic and 2 560 B of LDS fragment reads per edge, against 388 B of HBM traffic; in the power-limited regime
-// this kernel runs in that data movement is what is left to save (timing ablation of the streaming
-// kernel: 0.663 ms, 0.555 without the copies).  Here the dataflow is turned around:
+// this kernel runs in that data movement is what is left to save.  Here the dataflow is turned around:
 //  * ONE 256-thread workgroup per CU, one wave per SIMD, 512 registers per lane.  The four layers are cut into 15 "units"
-//    of one 32-feature out-tile (20 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
-//    80 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
+//    of one 32-feature out-tile (30 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
+//    110-120 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
 //    the whole launch — 300 KB of the CU's 512 KB register file hold the entire edge stack:
 //        wave 0: first layer (its 20 KB of fragments in LDS), RE1 tiles 0-2      wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
 //        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: We tiles 1-4
 //    Three units of a wave sit in the accumulation half of the register file (the MFMA reads its A operand from there
 //    directly), the fourth and all accumulators in the architectural half (the epilogue's VALU instructions read them directly).
-//  * 32-edge blocks flow through the waves as a software pipeline; a layer's 160 x 32 fp16 activation block (10 KB, already in
-//    the B-operand image of the next layer: lane (j, h) writes exactly the 16 bytes lane (j, h) of the consumer reads) is
-//    handed over through LDS: 10 KB written + 10-20 KB read per block and wave instead of 320 KB of weight fragments.
-//  * One barrier per ROUND (80 MFMAs per wave), every buffer a ring of three blocks.  Round r: wave 1 loads the edge indices
-//    of its block i = r, the node rows of i-1 and writes the input features of i-2; the first layer works on i-3, RE1 on
-//    i-4, RE2 on i-6, We on i-8.
-//  * A lone wave hides an instruction only in the shadow of ONE MFMA, and only ~3 of them (tools/ubench/mfma_lone.hip: 32-33
-//    cycles per MFMA with <= 3 VALU instructions per MFMA, 39.5 with 4.5; s_memtime: a 28-instruction epilogue queued behind
-//    four back-to-back MFMAs cost its full 110 cycles).  So the MFMAs are issued from
-//    inline asm as (lo, hi) pairs of one accumulator, and after EACH pair runs one "micro-chore" of the previous phase's
-//    epilogue: two accumulator values -> ReLU -> one packed fp16 convert (every fourth: the 16-byte store), or one piece
-//    of the input gather, pinned by sched_barrier.  The accumulators a chore reads were last written four or more MFMAs
-//    earlier (asm MFMAs get no hazard nops from the compiler).
-//  * Each accumulator still sees lo*x then hi*x by ascending k16-step, so results equal edge_encode_kernel<PrecH2> bit for bit.
+//  * 32-edge blocks flow through the waves as a software pipeline; a layer's 160 x 32 activation block is handed over through LDS
+//    as a SET of two images already in the B-operand layout of the next layer (lane (j, h) writes exactly the bytes lane (j, h) of
+//    the consumer reads): 10 KB of fp16 values and 5 KB of e5m2 residual bytes (PrecH3: x = x16 + r8).  15 KB written + 15-30 KB
+//    read per block and wave instead of 320 KB of weight fragments.  LDS: (2 + 3 + 3) sets + first-layer inputs and fragments = 146 KB.
+//  * One barrier per ROUND, the RE2 / We inputs in rings of three blocks, the RE1 input (written in round i + 3, read in round
+//    i + 4) in a ring of two.  Round r: wave 1 loads the edge indices of its block i = r, the node rows of i-1 and writes the
+//    input features of i-2; the first layer works on i-3, RE1 on i-4, RE2 on i-6, We on i-8.
+//  * A lone wave hides an instruction only in the shadow of an MFMA, and only ~3 of them per MFMA (tools/ubench/mfma_lone.hip: 32-33
+//    cycles per MFMA with <= 3 VALU instructions per MFMA, 39.5 with 4.5).  So the MFMAs are issued from inline asm as (lo.x, hi.x,
+//    hi.r) triples of one accumulator, and after EACH triple runs one "micro-chore" of the previous phase's epilogue: two accumulator
+//    values -> ReLU -> packed fp16 convert -> residual bytes (every fourth: the 16 + 8 byte stores), one piece of a q16 tile
+//    (block maximum, exponent, packed snorm16 converts, stores) or one piece of the input gather, pinned by sched_barrier.  The
+//    accumulators a chore reads were last written four or more MFMAs earlier (asm MFMAs get no hazard nops from the compiler).
+//  * Each accumulator sees lo*x16, hi*x16, hi*r8 by ascending k16-step, so results equal edge_encode_kernel<PrecH3> bit for bit.
 // =====================================================================================================================
-#define AG_WS_IMG 10240          // bytes of one activation image: [10 k16-steps][64 lanes][8 fp16]
+#define AG_WS_IMG 10240          // bytes of one fp16 activation image: [10 k16-steps][64 lanes][8 fp16]
+#define AG_WS_RES 5120           // bytes of its residual image: [10 k16-steps][64 lanes][8 e5m2]
+#define AG_WS_SET (AG_WS_IMG + AG_WS_RES)
 #define AG_WS_IN0 2048           // first-layer input image: 2 k16-steps
 #define AG_WS_SLOTS 3
-#ifndef AG_WS_ABL
-#define AG_WS_ABL 0           // timing-only ablations (debug builds): 1 = no epilogue / gather chores, 2 = chores without their LDS / global stores
-#endif
+#define AG_WS_SLOTS0 2           // ring of the RE1 input: produced in round i + 3, consumed in round i + 4
 #define AG_WS_LAG_F 3
 #define AG_WS_LAG_1 4
 #define AG_WS_LAG_2 6
 #define AG_WS_LAG_3 8
 
 typedef f16x8 WsUnit[10][2];     // A-operand fragments of one (layer, out-tile) unit: [k16-step][hi | lo]
-typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+typedef h3_u32x4 ws_u32x4;
+typedef int ws_i32x2 __attribute__((ext_vector_type(2)));
 
 // ACC: keep the unit in the accumulation-register half of the file; a wave holds three units (240 registers) there.
 template <bool ACC>
@@ -1094,10 +1094,25 @@ __device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, int
             else asm volatile("" : "+v"(W[u][hl]));
         }
 }
-template <int N>
-__device__ __forceinline__ void ws_wait(bf16x8 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int OFF>
+__device__ __forceinline__ void lds_read8(ws_i32x2 &d, unsigned lds_byte_addr)
+{
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_byte_addr), "n"(OFF));
+}
 template <int N>
 __device__ __forceinline__ void ws_wait2(bf16x8 &a, bf16x8 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void ws_wait_xr(bf16x8 &x, ws_i32x2 &r)
+{
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(r) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ws_wait_xr2(bf16x8 &x0, ws_i32x2 &r0, bf16x8 &x1, ws_i32x2 &r1)
+{
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x0), "+v"(r0), "+v"(x1), "+v"(r1) : "n"(N));
+}
 
 // acc (+)= W . x from inline asm: accumulator and B operand in architectural registers, A operand where the unit lives
 template <bool ACC, bool FIRST>
@@ -1112,17 +1127,25 @@ __device__ __forceinline__ void ws_mfma(f32x16 &acc, const f16x8 &w, const bf16x
     }
 }
 
-// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input image at LDS address la0, accumulators
-// [NA0, NA0 + NA1) the following units on the image at la1; units with index < NACC live in accumulation registers.
-// An accumulator's lo and hi MFMA of a k16-step are issued BACK TO BACK with nothing in between (the dependent MFMA then
-// uses the pipe's accumulate path; one MFMA of another chain in between leaves it waiting for the write-back: s_memtime,
-// 40 cycles per MFMA instead of 32), and the next pair on the same accumulator follows >= 2 MFMAs later.
-// slot(IC<p>) runs after pair p = u * NA + k (p = 0 .. 10 NA - 1).
-// The three-deep fragment ring q0 / q1 is the caller's: with NEXT_NIN > 0 the phase also issues the first two k16-steps of
-// the NEXT phase (NEXT_NIN input images at na0 / na1) during its own steps 8 and 9, and that phase is instantiated with
-// PRE = true and the ring offset RO = 1 (its step s sits in ring slot (s + RO) % 3): no exposed LDS round trip between phases.
+// operand rings of a wave: per input image a three-deep ring of fp16 fragments (16 bytes per lane and k16-step) and of residual bytes (8)
+struct WsRing {
+    bf16x8 q0[3], q1[3];
+    ws_i32x2 r0[3], r1[3];
+    unsigned lane8;              // lane * 8: the residual image of a set starts AG_WS_IMG bytes after the fp16 image, 8 bytes per lane
+    __device__ __forceinline__ unsigned res(unsigned la) const { return la + AG_WS_IMG - lane8; }      // la = set + lane * 16
+};
+
+// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input set at LDS address la0, accumulators
+// [NA0, NA0 + NA1) the following units on the set at la1; units with index < NACC live in accumulation registers.
+// An accumulator's three MFMAs of a k16-step (lo.x, hi.x, hi.r) are issued BACK TO BACK with nothing in between (the dependent MFMA
+// then uses the pipe's accumulate path; one MFMA of another chain in between leaves it waiting for the write-back: s_memtime,
+// 40 cycles per MFMA instead of 32), and the next triple on the same accumulator follows >= 3 MFMAs later.
+// slot(IC<p>) runs after triple p = u * NA + k (p = 0 .. 10 NA - 1).
+// With NEXT_NIN > 0 the phase also issues the first two k16-steps of the NEXT phase (NEXT_NIN input sets at na0 / na1) during its own
+// steps 8 and 9, and that phase is instantiated with PRE = true and the ring offset RO = 1 (its step s sits in ring slot
+// (s + RO) % 3): no exposed LDS round trip between phases.
 template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, class Slot>
-__device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0 + NA1], bf16x8 (&q0)[3], bf16x8 (&q1)[3], unsigned la0, unsigned la1,
+__device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0 + NA1], WsRing &G, unsigned la0, unsigned la1,
                                          unsigned na0, unsigned na1, Slot &&slot)
 {
     constexpr int NIN = NA1 ? 2 : 1, NA = NA0 + NA1;
@@ -1130,11 +1153,19 @@ __device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0
     auto issue = [&](auto S) {
         constexpr int s = decltype(S)::value;
         if constexpr (s < 10) {
-            lds_read16<s * 1024>(q0[(s + RO) % 3], la0);
-            if constexpr (NA1 > 0) lds_read16<s * 1024>(q1[(s + RO) % 3], la1);
+            lds_read16<s * 1024>(G.q0[(s + RO) % 3], la0);
+            lds_read8<s * 512>(G.r0[(s + RO) % 3], G.res(la0));
+            if constexpr (NA1 > 0) {
+                lds_read16<s * 1024>(G.q1[(s + RO) % 3], la1);
+                lds_read8<s * 512>(G.r1[(s + RO) % 3], G.res(la1));
+            }
         } else if constexpr (NEXT_NIN > 0) {
-            lds_read16<(s - 10) * 1024>(q0[(s + RO) % 3], na0);
-            if constexpr (NEXT_NIN > 1) lds_read16<(s - 10) * 1024>(q1[(s + RO) % 3], na1);
+            lds_read16<(s - 10) * 1024>(G.q0[(s + RO) % 3], na0);
+            lds_read8<(s - 10) * 512>(G.r0[(s + RO) % 3], G.res(na0));
+            if constexpr (NEXT_NIN > 1) {
+                lds_read16<(s - 10) * 1024>(G.q1[(s + RO) % 3], na1);
+                lds_read8<(s - 10) * 512>(G.r1[(s + RO) % 3], G.res(na1));
+            }
         }
     };
     if constexpr (!PRE) {
@@ -1142,60 +1173,73 @@ __device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0
         issue(std::integral_constant<int, 1>{});
     }
     static_for<0, 10>([&](auto U) {
-        constexpr int u = decltype(U)::value;
+        constexpr int u = decltype(U)::value, ri = (u + RO) % 3;
         issue(std::integral_constant<int, u + 2>{});
-        constexpr int n1 = (u + 1 < 10) ? NIN : NEXT_NIN, n2 = (u + 2 < 10) ? NIN : NEXT_NIN;      // reads issued after step u's
-        if constexpr (NA1 > 0) ws_wait2<n1 + n2>(q0[(u + RO) % 3], q1[(u + RO) % 3]); else ws_wait<n1 + n2>(q0[(u + RO) % 3]);
+        constexpr int n1 = (u + 1 < 10) ? NIN : NEXT_NIN, n2 = (u + 2 < 10) ? NIN : NEXT_NIN;      // input sets whose (two) reads were issued after step u's
+        if constexpr (NA1 > 0) ws_wait_xr2<2 * (n1 + n2)>(G.q0[ri], G.r0[ri], G.q1[ri], G.r1[ri]); else ws_wait_xr<2 * (n1 + n2)>(G.q0[ri], G.r0[ri]);
+        const bf16x8 x0 = G.q0[ri], x1 = NA1 > 0 ? G.q1[ri] : G.q0[ri];
+        bf16x8 rx0 = __builtin_bit_cast(bf16x8, h3_expand(G.r0[ri][0], G.r0[ri][1]));
+        bf16x8 rx1 = rx0;
+        if constexpr (NA1 > 0) rx1 = __builtin_bit_cast(bf16x8, h3_expand(G.r1[ri][0], G.r1[ri][1]));
+        // An MFMA that reads a register a VALU instruction has just written needs two wait states (the compiler inserts them for builtin
+        // MFMAs; the hazard recogniser does not look inside asm): the byte permutes are pinned here, ahead of the step's first MFMA.
+        if constexpr (NA1 > 0) asm volatile("s_nop 1" : "+v"(rx0), "+v"(rx1)); else asm volatile("s_nop 1" : "+v"(rx0));
         static_for<0, NA>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            ws_mfma<(U0 + k < NACC), (u == 0)>(acc[k], W[U0 + k][u][1], k < NA0 ? q0[(u + RO) % 3] : q1[(u + RO) % 3]);      // lo
-            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? q0[(u + RO) % 3] : q1[(u + RO) % 3]);         // hi
-            if constexpr (!(AG_WS_ABL & 1)) slot(std::integral_constant<int, u * NA + k>{});
+            ws_mfma<(U0 + k < NACC), (u == 0)>(acc[k], W[U0 + k][u][1], k < NA0 ? x0 : x1);      // lo . x16
+            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? x0 : x1);         // hi . x16
+            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? rx0 : rx1);       // hi . r8
+            slot(std::integral_constant<int, u * NA + k>{});
             __builtin_amdgcn_sched_barrier(0);
         });
     });
 }
 
-// Epilogue micro-chores.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values).
-// Hidden layers: ReLU, packed fp16 convert; the fourth dword stores the consumer's 16 bytes (bias column: feature 150 := 1.0).
+// Epilogue micro-chores of the hidden layers.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values):
+// ReLU, packed fp16 convert, largest-pattern tracking, the two residual bytes (h3_pair); the fourth dword stores the consumer's 16 bytes
+// of k16-step 2T + S (bias column: feature 150 := 1.0) and its 8 residual bytes.
+struct WsEpi { ws_u32x4 H; int R0, R1; unsigned bad; };
 template <int T, int M>
-__device__ __forceinline__ void ws_act_micro(const f32x16 &acc, ws_u32x4 &H, unsigned char *img_lane, int h)
+__device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, unsigned char *set_lane, unsigned lane8, int h)
 {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     constexpr int S = M >> 2, w = M & 3;
-    const f32x2 x = {relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1])};
-    H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    E.H[w] = h3_pair(relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1]), w < 2 ? E.R0 : E.R1, (w & 1) != 0, E.bad);
     if constexpr (w == 3) {
-        if constexpr (T == 4 && S == 1) {           // feature 150 = 16*9 + 6: element e = 2 of the h = 1 half
-            if (h == 1) H[1] = (H[1] & 0xffff0000u) | 0x3c00u;
+        if constexpr (T == 4 && S == 1) {           // feature 150 = 16*9 + 6: element e = 2 of the h = 1 half (its residual byte is 0: the feature is padding)
+            if (h == 1) E.H[1] = (E.H[1] & 0xffff0000u) | 0x3c00u;
         }
-        if (!(AG_WS_ABL & 2) || H[0] == 0x12345678u) *reinterpret_cast<ws_u32x4 *>(img_lane + (2 * T + S) * 1024) = H;
+        *reinterpret_cast<ws_u32x4 *>(set_lane + (2 * T + S) * 1024) = E.H;
+        *reinterpret_cast<ws_i32x2 *>(set_lane + AG_WS_IMG - lane8 + (2 * T + S) * 512) = ws_i32x2{E.R0, E.R1};
     }
 }
-// We: packed fp16 convert of the raw values; `bad` keeps the largest |fp16| bit pattern per half-word (>= 0x7c00: inf or NaN,
-// i.e. |v| > 65504 or a non-finite accumulator); the fourth dword stores 16 bytes of the Eterm row, the last one of a tile tests `bad`.
-template <int T, int M>
-__device__ __forceinline__ void ws_eterm_micro(const f32x16 &acc, ws_u32x4 &H, unsigned &bad, _Float16 *row)
+// We: one out-tile of the q16 table in seven chores (format and helpers: RowStoreQ16Epi above): 0, 1 the lane's maximum over its 16 values,
+// 2 the tile exponent (partner half by v_permlane32_swap) and its byte, 3..6 two packed converts each, 4 and 6 store 16 (8) bytes.
+// Branch-free on purpose: a store under `if (block is valid)` made the compiler sink the whole tile's converts into the conditional block.
+// Rows of blocks outside the launch go to 32 dump rows behind the table (the 16-bit table uses half of its fp32-sized allocation).
+struct WsQ16 { unsigned m; int eb; float inv; unsigned w[4]; unsigned nonfinite; };
+template <int T, int C>
+__device__ __forceinline__ void ws_q16_chore(const f32x16 &acc, WsQ16 &Q, unsigned char *row, int h)
 {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    constexpr int S = M >> 2, w = M & 3;
-    const f32x2 x = {acc[8 * S + 2 * w], acc[8 * S + 2 * w + 1]};
-    H[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
-    bad = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, bad), __builtin_bit_cast(u16x2, H[w] & 0x7fff7fffu)));
-    if constexpr (w == 3) {
-        if (!(AG_WS_ABL & 2) || H[0] == 0x12345678u) *reinterpret_cast<ws_u32x4 *>(row + 32 * T + 8 * S) = H;
+    static_assert(C >= 0 && C < 7, "seven chores per out-tile");
+    if constexpr (C == 0) {
+        Q.m = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) Q.m = q16_max2(Q.m, acc[r], acc[r + 1]);
+    } else if constexpr (C == 1) {
+#pragma unroll
+        for (int r = 8; r < 16; r += 2) Q.m = q16_max2(Q.m, acc[r], acc[r + 1]);
+    } else if constexpr (C == 2) {
+        bool nf;
+        Q.eb = q16_tile_exp(Q.m, nf);
+        Q.inv = q16_inv_scale(Q.eb);
+        Q.nonfinite |= nf ? 1u : 0u;
+        q16_store_exp(row, T, h, Q.eb);
+    } else {
+        constexpr int s = (C - 3) >> 1, k0 = 2 * ((C - 3) & 1);
+        Q.w[k0] = q16_pack(acc[8 * s + 2 * k0], acc[8 * s + 2 * k0 + 1], Q.inv);
+        Q.w[k0 + 1] = q16_pack(acc[8 * s + 2 * k0 + 2], acc[8 * s + 2 * k0 + 3], Q.inv);
+        if constexpr (((C - 3) & 1) == 1) q16_store_half(row, T, h, s, Q.w);
     }
-}
-// Branch-free on purpose: a store under `if (block is valid)` made the compiler sink the whole tile's converts into the
-// conditional block (one 30-instruction lump instead of eight micro-chores).  Rows of blocks outside the launch go to 32 dump
-// rows behind the table (the fp16 table uses half of its fp32-sized allocation); `bad` is tested once, when the wave is done
-// (every LDS buffer starts zeroed, so rounds of the pipeline's fill and drain convert finite values).
-__device__ __forceinline__ void ws_report(unsigned bad, int *status)
-{
-    if (((bad + 0x04000400u) & 0x80008000u) && status) atomicOr(status, 1);     // AG_STATUS_NONFINITE
 }
 
 // End of a round: LDS writes of this wave landed, then the workgroup barrier.  NOT __syncthreads(): its workgroup-scope fence also
@@ -1233,11 +1277,13 @@ __global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a)
 
 __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_act[3][AG_WS_SLOTS][AG_WS_IMG];   // inputs of RE1, RE2, We: rings of three blocks
+    __shared__ __attribute__((aligned(16))) unsigned char s_act0[AG_WS_SLOTS0][AG_WS_SET];    // input sets of RE1 (ring of two blocks)
+    __shared__ __attribute__((aligned(16))) unsigned char s_act12[2][AG_WS_SLOTS][AG_WS_SET]; // ... of RE2 and We (rings of three)
     __shared__ __attribute__((aligned(16))) unsigned char s_in0[AG_WS_SLOTS][AG_WS_IN0];      // first-layer inputs
     __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane8 = lane * 8;
     const int Mn = a.B * a.N;
     const int E = a.row_ptr[Mn];
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
@@ -1247,31 +1293,31 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     const int rounds = n_i + AG_WS_LAG_3 + 2;
     const float4 *ws = w.edge_encode_h2;
     for (int i = tid; i < AG_CHUNK_F4; i += 256) s_wf[i] = ws[i];
-    for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 256) reinterpret_cast<float4 *>(&s_act[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (int)(sizeof(s_act0) / 16); i += 256) reinterpret_cast<float4 *>(&s_act0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (int)(sizeof(s_act12) / 16); i += 256) reinterpret_cast<float4 *>(&s_act12[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 256) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
     auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
     auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
-    auto img = [&](int layer, int i) { return &s_act[layer][slot_of(i)][lane * 16]; };        // this lane's 16 bytes of k16-step 0
+    // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i
+    auto img = [&](int layer, int i) -> unsigned char * {
+        return layer == 0 ? &s_act0[(i + 12) % AG_WS_SLOTS0][lane * 16] : &s_act12[layer - 1][slot_of(i)][lane * 16];
+    };
     auto block_ok = [&](int i) { return i >= 0 && i < n_i; };
     auto eterm_row = [&](int i) {
         const size_t e = (block_ok(i) ? (size_t)gblock(i) * 32 : e_pad) + j;
-        return reinterpret_cast<_Float16 *>(a.eterm) + e * AG_FP + 16 * h;
+        return reinterpret_cast<unsigned char *>(a.eterm) + e * (2 * AG_FP);
     };
     WsUnit W[4];
-    ws_u32x4 H = {0u, 0u, 0u, 0u};
-    // accumulators start at zero: the first rounds' chores convert them before any MFMA has written them (register garbage would raise `bad`)
+    WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
+    WsRing G;
+    G.lane8 = lane8;
+    // accumulators start at zero: the first rounds' chores convert them before any MFMA has written them
     auto zero = [](auto &arr) {
         for (auto &v : arr)
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = 0.0f;
     };
-#if AG_TRACE
-    int tr = 0;
-#define WS_STAMP(TAG) do { if (blockIdx.x == 3 && r >= 100 && r < 108 && tr < 256) { ag_trace_buf[wave * 512 + 2 * tr] = (TAG); ag_trace_buf[wave * 512 + 2 * tr + 1] = __builtin_readcyclecounter(); ++tr; } } while (0)
-#else
-#define WS_STAMP(TAG) do { } while (0)
-#endif
 
     if (wave == 0) {
         // ---------------------------------------------------------------- first layer, RE1 tiles 0-2
@@ -1283,19 +1329,18 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         const unsigned wf = lds_addr_of(s_wf) + lane * 16;
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            WS_STAMP(1);
             const int i0 = r - AG_WS_LAG_F, i1 = r - AG_WS_LAG_1;
             unsigned char *outF = img(0, i0), *outPp = img(1, i1 - 1);
-            // first layer of block i0: 5 out-tiles x 2 k16-steps x (lo, hi), A fragments from LDS (five independent chains);
-            // shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores in 20 slots)
+            // first layer of block i0: 5 out-tiles x 2 k16-steps x (lo, hi), A fragments from LDS (five independent chains; two products:
+            // the inputs carry their own residuals in spare K slots);  shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores in 20 slots)
             {
                 const unsigned lin = lds_addr_of(&s_in0[slot_of(i0)][lane * 16]);
                 bf16x8 xq[2], fq[2][5];
                 lds_read16<0>(xq[0], lin);
                 lds_read16<1024>(xq[1], lin);
                 static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + 0) * 2 + 1) * 1024>(fq[0][t], wf); });
-                static_for<0, 4>([&](auto G) {
-                    constexpr int g = decltype(G)::value, u = g >> 1;          // groups: (u0, lo) (u0, hi) (u1, lo) (u1, hi)
+                static_for<0, 4>([&](auto GG) {
+                    constexpr int g = decltype(GG)::value, u = g >> 1;          // groups: (u0, lo) (u0, hi) (u1, lo) (u1, hi)
                     if constexpr (g < 3) {
                         constexpr int nu = (g + 1) >> 1, nhl = 1 - ((g + 1) & 1);
                         static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + nu) * 2 + nhl) * 1024>(fq[(g + 1) & 1][t], wf); });
@@ -1307,32 +1352,28 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
                         ws_mfma<false, (g == 0)>(accF[t], __builtin_bit_cast(f16x8, fq[g & 1][t]), xq[u]);
                         constexpr int m = g * 5 + t;                           // 0..19
                         if constexpr (m < 4) {                                 // two micro-chores in the first four slots
-                            ws_act_micro<0, 2 * m>(accP[0], H, outPp, h);
-                            ws_act_micro<0, 2 * m + 1>(accP[0], H, outPp, h);
+                            ws_act_micro<0, 2 * m>(accP[0], Ep, outPp, lane8, h);
+                            ws_act_micro<0, 2 * m + 1>(accP[0], Ep, outPp, lane8, h);
                         } else {
                             constexpr int c = m + 4;                           // 8..23
-                            ws_act_micro<c / 8, c % 8>(accP[c / 8], H, outPp, h);
+                            ws_act_micro<c / 8, c % 8>(accP[c / 8], Ep, outPp, lane8, h);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             }
-            WS_STAMP(2);
             const unsigned la = lds_addr_of(img(0, i1));
-            bf16x8 q0[3], q1[3];
-            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, q0, q1, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish the first layer (40 micro-chores in 30 slots)
+            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, G, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish the first layer (40 micro-chores in 30 slots)
                 constexpr int p = decltype(PP)::value;
                 if constexpr (p < 10) {
-                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], H, outF, h);
-                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], H, outF, h);
+                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], Ep, outF, lane8, h);
+                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], Ep, outF, lane8, h);
                 } else {
                     constexpr int c = p + 10;                           // 20..39
-                    ws_act_micro<c / 8, c % 8>(accF[c / 8], H, outF, h);
+                    ws_act_micro<c / 8, c % 8>(accF[c / 8], Ep, outF, lane8, h);
                 }
             });
-            WS_STAMP(3);
             ws_round_barrier();
-            WS_STAMP(4);
         }
     } else if (wave == 1) {
         // ---------------------------------------------------------------- RE1 tiles 3-4, RE2 tiles 0-1, per-edge input gather
@@ -1343,7 +1384,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
-        // The gather of one block's inputs (model.py:220-253) is cut into pieces of a few instructions, one per MFMA-pair slot,
+        // The gather of one block's inputs (model.py:220-253) is cut into pieces of a few instructions, one per MFMA-triple slot,
         // three blocks in flight: edge indices (this round) -> the two 64-byte node rows (next round) -> features (the round after).
         int er = 0, es = 0;                // indices of block r (loaded in round r, used in round r + 1)
         float4 R[4], S[4];                 // receiver / sender rows of block r - 1 (loaded in round r, used in round r + 1)
@@ -1354,18 +1395,17 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float x0, float x1) { const f32x2 v = {x0, x1}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); };
         ws_u32x4 X1 = {0u, 0u, 0u, 0u};      // k16-step 1 of the block's first-layer input image
         const float4 *tab = reinterpret_cast<const float4 *>(a.edge_node_tab);
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            WS_STAMP(1);
             const int i1 = r - AG_WS_LAG_1, i2 = r - AG_WS_LAG_2;
             const unsigned la1 = lds_addr_of(img(0, i1)), la2 = lds_addr_of(img(1, i2));
             unsigned char *out1 = img(1, i1), *out2p = img(2, i2 - 1);
-            bf16x8 q0[3], q1[3];
-            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, q0, q1, la1, la1, la2, la2, [&](auto PP) {      // RE1 tiles 3, 4;  shadow: finish RE2 tiles 0, 1 of the previous block
+            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la1, la1, la2, la2, [&](auto PP) {      // RE1 tiles 3, 4;  shadow: finish RE2 tiles 0, 1 of the previous block
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], H, out2p, h);
+                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], Ep, out2p, lane8, h);
                 // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1]
                 if constexpr (p == 14) {
                     feat[0] = R[0].x; feat[1] = R[0].y; feat[2] = S[0].x; feat[3] = S[0].y; feat[4] = fabsf(R[0].z - S[0].z); feat[AG_EDGE_IN] = 1.0f;
@@ -1375,34 +1415,31 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
                     feat[9] = R[2].x - S[2].x; feat[10] = R[2].y - S[2].y; feat[11] = R[2].z - S[2].z; feat[12] = R[2].w - S[2].w;
                     feat[13] = R[3].x - S[3].x; feat[14] = R[3].y - S[3].y; feat[15] = R[3].z - S[3].z; feat[16] = R[3].w - S[3].w;
                 }
-                // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (16, the bias 1.0, then the fp16
-                // residuals of features 14..16 in slots 18..20: f16_residual; the same values in the same slots as edge_encode_kernel<PrecH2>)
+                // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (slot 16: feature 16, 17: the bias
+                // 1.0, 18..29: the fp16 residuals of features 5..16, f16_residual; the same values in the same slots as edge_encode_kernel<PrecH3>)
                 if constexpr (p == 16) {
                     ws_u32x4 X;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) {
-                            const f32x2 v = {h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]};
-                            X[2 * q + c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-                        }
+                        for (int c2 = 0; c2 < 2; ++c2)
+                            X[2 * q + c2] = pk(h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]);
                     *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16]) = X;
                 }
-                if constexpr (p == 17) {        // slots 16, 17 (h = 0) | 20, 21 (h = 1) and 18, 19 | 22, 23; slots 24..31 stay zero
-                    const float r16 = f16_residual(feat[16]);
-                    const f32x2 v0 = {h ? r16 : feat[16], h ? 0.0f : feat[AG_EDGE_IN]};
-                    const f32x2 s1 = {h ? 0.0f : feat[14], h ? 0.0f : feat[15]};
-                    const f32x2 v1 = {f16_residual(s1[0]), f16_residual(s1[1])};
-                    X1[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, f16x2));
-                    X1[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, f16x2));
+                if constexpr (p == 17) {        // slots 16, 17 | 20, 21 and 18, 19 | 22, 23   (h = 0 | h = 1)
+                    X1[0] = h ? pk(f16_residual(feat[7]), f16_residual(feat[8])) : pk(feat[16], feat[AG_EDGE_IN]);
+                    X1[1] = h ? pk(f16_residual(feat[9]), f16_residual(feat[10])) : pk(f16_residual(feat[5]), f16_residual(feat[6]));
+                }
+                if constexpr (p == 18) {        // slots 24, 25 | 28, 29 and 26, 27 | 30, 31 (slots 30, 31 stay zero)
+                    X1[2] = h ? pk(f16_residual(feat[15]), f16_residual(feat[16])) : pk(f16_residual(feat[11]), f16_residual(feat[12]));
+                    X1[3] = h ? 0u : pk(f16_residual(feat[13]), f16_residual(feat[14]));
                     *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024]) = X1;
                 }
             });
-            WS_STAMP(2);
             static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
-            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, q0, q1, la2, la2, la2, la2, [&](auto PP) {      // RE2 tiles 0, 1;  shadow: finish RE1 tiles 3, 4
+            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la2, la2, la2, la2, [&](auto PP) {      // RE2 tiles 0, 1;  shadow: finish RE1 tiles 3, 4
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], H, out1, h);
+                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], Ep, out1, lane8, h);
                 // node rows of block r - 1 (indices loaded last round): 2 x 64 bytes, one 16-byte load per piece
                 if constexpr (p >= 6 && p < 14) {
                     constexpr int q = (p - 6) & 3;
@@ -1416,9 +1453,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
                     es = valid ? a.edge_send[e] : 0;
                 }
             });
-            WS_STAMP(3);
             ws_round_barrier();
-            WS_STAMP(4);
         }
     } else if (wave == 2) {
         // ---------------------------------------------------------------- RE2 tiles 2-4, We tile 0
@@ -1428,30 +1463,25 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
-        unsigned bad = 0;
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0.0f, {0u, 0u, 0u, 0u}, 0u};
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            WS_STAMP(1);
             const int i2 = r - AG_WS_LAG_2, i3 = r - AG_WS_LAG_3;
             const unsigned la2 = lds_addr_of(img(1, i2)), la3 = lds_addr_of(img(2, i3));
             unsigned char *out2 = img(2, i2), *out2p = img(2, i2 - 1);
-            _Float16 *rowp = eterm_row(i3 - 1);
-            bf16x8 q0[3], q1[3];
-            ws_phase<0, 2, 0, 3, false, 0, 2>(W, accP, q0, q1, la2, la2, la2, la3, [&](auto PP) {      // RE2 tiles 2, 3;  shadow: finish RE2 tile 4 and We tile 0 of the previous blocks
+            unsigned char *rowp = eterm_row(i3 - 1);
+            ws_phase<0, 2, 0, 3, false, 0, 2>(W, accP, G, la2, la2, la2, la3, [&](auto PP) {      // RE2 tiles 2, 3;  shadow: finish RE2 tile 4 and We tile 0 of the previous blocks
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], H, out2p, h);
-                if constexpr (p >= 8 && p < 16) ws_eterm_micro<0, p - 8>(accQ[1], H, bad, rowp);
+                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], Ep, out2p, lane8, h);
+                if constexpr (p >= 8 && p < 15) ws_q16_chore<0, p - 8>(accQ[1], Q, rowp, h);
             });
-            WS_STAMP(2);
-            ws_phase<2, 1, 1, 3, true, 1, 0>(W, accQ, q0, q1, la2, la3, la2, la3, [&](auto PP) {      // RE2 tile 4 + We tile 0
+            ws_phase<2, 1, 1, 3, true, 1, 0>(W, accQ, G, la2, la3, la2, la3, [&](auto PP) {      // RE2 tile 4 + We tile 0
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], H, out2, h);
+                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], Ep, out2, lane8, h);
             });
-            WS_STAMP(3);
             ws_round_barrier();
-            WS_STAMP(4);
         }
-        ws_report(bad, a.status);
+        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
     } else {
         // ---------------------------------------------------------------- We tiles 1-4
 #pragma unroll
@@ -1460,35 +1490,28 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
-        unsigned bad = 0;
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0.0f, {0u, 0u, 0u, 0u}, 0u};
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            WS_STAMP(1);
             const int i3 = r - AG_WS_LAG_3;
             const unsigned la3 = lds_addr_of(img(2, i3));
-            _Float16 *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
-            bf16x8 q0[3], q1[3];
-            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, q0, q1, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: store We tiles 3, 4 of the previous block
+            unsigned char *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
+            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: store We tiles 3, 4 of the previous block
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_eterm_micro<3 + p / 8, p % 8>(accQ[p / 8], H, bad, rowp);
+                if constexpr (p < 7) ws_q16_chore<3, p>(accQ[0], Q, rowp, h);
+                if constexpr (p >= 10 && p < 17) ws_q16_chore<4, p - 10>(accQ[1], Q, rowp, h);
             });
-            WS_STAMP(2);
-            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, q0, q1, la3, la3, la3, la3, [&](auto PP) {      // We tiles 3, 4;  shadow: store We tiles 1, 2
+            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 3, 4;  shadow: store We tiles 1, 2
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_eterm_micro<1 + p / 8, p % 8>(accP[p / 8], H, bad, row);
+                if constexpr (p < 7) ws_q16_chore<1, p>(accP[0], Q, row, h);
+                if constexpr (p >= 10 && p < 17) ws_q16_chore<2, p - 10>(accP[1], Q, row, h);
             });
-            WS_STAMP(3);
             ws_round_barrier();
-            WS_STAMP(4);
         }
-        ws_report(bad, a.status);
+        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
     }
+    h3_report(Ep.bad, a.status);
 }
-
-#ifdef AG_EXPERIMENTS
-#include "experiments/ag_mlp_edge_nb_kernel.inc"
-#include "experiments/ag_mlp_ws8.inc"      // edge_encode_ws8_kernel: eight-wave weight-stationary kernel with PrecH6's arithmetic
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // One propagation round at node level: fused segment reduce (aggregate_rows) or a pre-computed `agg` table,
@@ -1533,16 +1556,17 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 
         typename Prec::Act x, y;
         if constexpr (FUSE) {
-            const int slot = tid / 20, c = tid - slot * 20, f0 = ag_half_lane_feature(c);
+            const int ng = lane / AG_AGG_GROUP, c = lane - ng * AG_AGG_GROUP, f0 = ag_half_lane_feature(c);      // twenty lanes of one wave per node
+            const int slot = wave * AG_AGG_NODES_PER_WAVE + ng;                                                      // 12 node slots per pass
 #pragma unroll 1
             for (int grp = 0; grp < AG_MLP_WAVES; ++grp) {
 #pragma unroll 1
                 for (int pass = 0; pass < 3; ++pass) {                   // 3 x 12 node slots >= 32 rows
                     const int r = pass * 12 + slot;
-                    if (tid < 240 && r < 32) {
+                    if (ng < AG_AGG_NODES_PER_WAVE && r < 32) {
                         const int gn = tile * AG_ROWS_PER_BLOCK + grp * 32 + r;
                         float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-                        if (gn < Mn) ag_reduce_node_half(a, gn, c, acc0, acc1);
+                        if (gn < Mn) ag_reduce_node_q16(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;
                     }
@@ -1564,10 +1588,6 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             }
         } else {
             f32x16 agg[AG_NT];
-#ifdef AG_EXPERIMENTS
-            if (a.fuse_agg) { if (a.eterm_half) aggregate_rows<true>(a, gc, valid, h, agg); else aggregate_rows<false>(a, gc, valid, h, agg); }
-            else
-#endif
             load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
 #pragma unroll
             for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
@@ -1603,11 +1623,6 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                     pm[c] = mv;
                     pp[c] = cur[c] + fminf(fmaxf(mv, -a.clamp), a.clamp);   // model.py:309
                 }
-            }
-            // precision mode 2 outside the motion range its 1e-4 deviation was validated on (ag_common.h): say so instead of passing it on
-            if (a.eterm_half && a.status) {
-                const bool big = valid && h == 0 && i < a.n_p && fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fabsf(m[2])) > AG_FAST_ENVELOPE;
-                if (__any(big) && (threadIdx.x & 63) == 0) atomicOr(a.status, 2);     // AG_STATUS_FAST_ENVELOPE, one atomic per wave
             }
         }
         q.next();
@@ -1809,12 +1824,6 @@ __global__ __launch_bounds__(256) void train_pack_b3_kernel(const float *W, cons
 
 }  // namespace
 
-#if AG_TRACE
-extern "C" __attribute__((visibility("default"))) int ag_debug_trace_read(unsigned long long *dst)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ag_trace_buf), sizeof(unsigned long long) * 4 * 512);
-}
-#endif
 
 static inline int grid_for(int rows, int max_blocks)
 {
@@ -1843,42 +1852,11 @@ void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     else hipLaunchKernelGGL((node_encode_kernel<PrecF32, false>), grid, block, 0, s, w, a);
 }
 
-#ifdef AG_EXPERIMENTS
-void ag_launch_pack_lo6(const float *W, int ld, int col0, int K, int n_out, const float *bias, float *chunks, hipStream_t s)
-{
-    hipLaunchKernelGGL(pack_lo6_kernel, dim3(AG_NT * 3), dim3(64), 0, s, W, ld, col0, K, n_out, bias, chunks);
-}
-#endif
 
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {
     if (a.e_cap <= 0) return;
-#ifdef AG_EXPERIMENTS     // edge_rows 64 / 33 / 34: the lone-wave split-bf16 pipelines (experiments/ag_mlp_edge_nb_kernel.inc)
-    if (a.precision == AG_PREC_B3 && a.edge_rows == 64 && a.tile_ctr) {     // one 512-register workgroup per CU
-        const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
-        const dim3 grid64(tiles < slots ? tiles : (slots > 0 ? slots : 1));
-        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 2, 4>), grid64, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 2, 4>), grid64, dim3(256), 0, s, w, a);
-        return;
-    }
-    if (a.precision == AG_PREC_B3 && a.edge_rows == 33 && a.tile_ctr) {     // 32 rows per wave on the lone-wave pipeline, two workgroups per CU
-        const dim3 grid32(grid_for(a.e_cap, a.max_blocks));
-        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1, 4>), grid32, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1, 4>), grid32, dim3(256), 0, s, w, a);
-        return;
-    }
-    if (a.precision == AG_PREC_B3 && a.edge_rows == 34 && a.tile_ctr) {     // eight 32-row waves sharing one ring, one workgroup per CU
-        const int tiles = (a.e_cap + 255) / 256, slots = a.max_blocks / AG_MLP_WG_PER_CU;
-        const dim3 grid8(tiles < slots ? tiles : (slots > 0 ? slots : 1));
-        if (a.eterm_half) hipLaunchKernelGGL((edge_encode_nb_kernel<true, 1, 8>), grid8, dim3(512), 0, s, w, a);
-        else hipLaunchKernelGGL((edge_encode_nb_kernel<false, 1, 8>), grid8, dim3(512), 0, s, w, a);
-        return;
-    }
-#endif
     const dim3 block(AG_MLP_THREADS);
-#ifdef AG_EXPERIMENTS
-    if (ag_launch_edge_encode_h6(w, a, s)) return;      // edge_products 1: the block-scaled fp6 correction product (experiments/ag_mlp_ws8.inc)
-#endif
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
@@ -1886,8 +1864,8 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(256), 0, s, w, a);   // (always four waves, whatever AG_MLP_THREADS is)
             return;
         }
-        const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H2_WG_PER_CU));
-        hipLaunchKernelGGL(edge_encode_kernel<PrecH2>, grid, block, 0, s, w, a);
+        const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H3_WG_PER_CU));
+        hipLaunchKernelGGL(edge_encode_kernel<PrecH3>, grid, block, 0, s, w, a);
         return;
     }
     const dim3 grid(grid_for(a.e_cap, a.max_blocks));

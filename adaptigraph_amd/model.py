@@ -119,28 +119,24 @@ class DynamicsPredictor(nn.Module):
 
     def take_status(self, device=None):
         """Read-and-clear the model's sticky numeric status (ag_model_status; synchronises the current stream).
-        Bit 0: a non-finite message sum was produced — with finite inputs, an fp16 overflow of the per-edge table in
-        precision mode 2.  Bit 1: a mode-2 forward predicted a motion component above 0.125, the range that mode's 1e-4
-        deviation is validated on (include/adaptigraph_hip.h).  Warns once per occurrence and returns the flag word."""
+        Bit 0: a forward left the range of its arithmetic — in precision mode 2 an fp16 activation of the edge stack beyond
+        65504 or a non-finite per-edge term, in any mode non-finite inputs (include/adaptigraph_hip.h).  Warns once per
+        occurrence and returns the flag word."""
         dev = torch.device(device if device is not None else self.device)
         flags = ctypes.c_int(0)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().ag_model_status(self.handle(dev), ctypes.byref(flags), _stream_ptr(dev)), "ag_model_status")
         if flags.value & 1:
-            warnings.warn("adaptigraph_amd: a forward produced non-finite message sums. If the inputs were finite, the fp16 "
-                          "per-edge table of precision mode 2 ('fast') overflowed (|Eterm| > 65504): use "
+            warnings.warn("adaptigraph_amd: a forward produced non-finite values. If the inputs were finite, an activation of the fp16 "
+                          "edge stack of precision mode 2 ('fast') left fp16's range (|x| > 65504): use "
                           "model.set_option('precision', 1).", RuntimeWarning, stacklevel=2)
-        if flags.value & 2:
-            warnings.warn("adaptigraph_amd: a forward in precision mode 2 ('fast') predicted a per-step motion above 0.125. That mode "
-                          "deviates from the fp32 forward by about 5e-4 of the largest motion, so the 1e-4 max-abs gate is not guaranteed "
-                          "at this motion size: model.set_option('precision', 1) holds it (<= 6e-6) at any size.", RuntimeWarning, stacklevel=2)
         return flags.value
 
     def set_option(self, name, value, device=None):
         """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16 with an
-        fp32 per-edge table, 2 = split-bf16 node stacks + two-product fp16 edge stack + per-edge table stored as fp16 ("fast",
-        the default: all three pass the 1e-4 gate on the reference forwards; 2 can overflow for |Eterm| > 65504, see
-        take_status); "rollout_streams"; "node_dedup"; "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"."""
+        fp32 per-edge table, 2 = split-bf16 node stacks + fp16 edge stack with residual bytes + 16-bit block-scaled per-edge
+        table ("fast", the default; its fp16 activations have fp16's range, see take_status); "rollout_streams"; "node_dedup";
+        "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"."""
         dev = torch.device(device if device is not None else self.device)
         _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
         return self

@@ -59,38 +59,33 @@ int ag_model_destroy(ag_model *m);
 
 /* Engine knobs (all have sane defaults; used by bench.py for A/B passes):
  *   "rollout_streams"  1..4  ag_rollout runs the batch as this many independent parts on separate streams (2)
- *   "fuse_aggregate"   0/1/2 segment reduce as its own HBM-streaming kernel (0, default), inside node_update row-per-lane (1, slower),
- *                            or inside node_update through an LDS stage (2, precision 2 only: no `agg` table; measured equal solo, -4 % co-run)
+ *   "fuse_aggregate"   0/2   segment reduce as its own HBM-streaming kernel (0, default) or inside node_update through an LDS stage
+ *                            (2, precision 2 only: no `agg` table; measured equal solo, -4 % in the two-stream rollout); bit-identical results
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
- *   "edge_products"    2/3   precision 2 only: MFMAs per fp32 product in the EDGE stack: 2 = fp16 activations x split-fp16 weights (default;
- *                            models whose edge weights exceed the fp16 range keep 3), 3 = split-bf16 like precision 1
- *                            (1 = the second of the two products on block-scaled fp6 MFMAs, same deviations: an experiment, compiled only into
- *                            -DAG_EXPERIMENTS builds, csrc/experiments/ag_mlp_h6.inc; the product library refuses it)
+ *   "edge_products"    2/3   precision 2 only: arithmetic of the EDGE stack: 2 = fp16 (default: split-fp16 weights x fp16 activations + an e5m2
+ *                            residual byte per activation, three fp16 MFMAs per fp32 product; models whose edge weights exceed the fp16 range
+ *                            keep 3), 3 = split-bf16 like precision 1
  *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
  *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
  *   "node_dedup"       0/1/2 particle_encoder / hoisted Pn / the first round's Hr, Hs computed once per DISTINCT [attrs | phys | action] row of a sample
  *                            (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout call: 1 (default) =
  *                            where it pays (>= 32 768 node-rows x steps per call), 2 = always, 0 = never (once per node and model step).
  *                            Bit-identical results
- *   "edge_rows"        32    (33/34/64, "fuse_aggregate" 1 and "aggregate_stream" 1 select kernels that were measured slower and are compiled only into
- *                            -DAG_EXPERIMENTS builds, csrc/experiments/; the product library refuses them)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
- *                            fp32 accumulate; 1e-6..6e-6 abs deviation on the reference forwards, gate 1e-4);
- *                            2 = mode 1 for the node-level stacks, the edge stack on two fp16 products per fp32 product and the per-edge
- *                            Eterm table stored as fp16 (4e-6..9.4e-6 on default-initialised weights, 8e-6..4.7e-5 on weights trained by the
- *                            reference's train(); precision 1 measures <= 1.2e-6 on those) (default 2) */
+ *                            fp32 accumulate; 1e-6..8e-6 abs deviation from the reference forward, gate 1e-4);
+ *                            2 (default) = mode 1 for the node-level stacks, the edge stack in fp16 with residual bytes ("edge_products" 2) and the
+ *                            per-edge Eterm table in 16-bit block-scaled fixed point (q16: half the dominant HBM stream); the same deviation
+ *                            class as mode 1 at any motion size (random sweeps, trained weights, actions up to +-0.5) */
 int ag_set_option(ag_model *m, const char *name, int value);
 
-/* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on
- * this model produced a non-finite message sum.  With finite inputs that is an overflow of the fp16 per-edge table of
- * precision mode 2 (|Eterm| > 65504, possible with a trained checkpoint whose activations are large): switch the model
- * to precision 1.  (An overflow of a HIDDEN fp16 activation of that mode's edge stack can be swallowed by the next layer's ReLU and is not
- * guaranteed to be reported: precision 1 is the setting for checkpoints with an unknown activation range.)
- * Bit 1 (AG_STATUS_FAST_ENVELOPE) = a precision-mode-2 forward predicted a motion component larger than 0.125.  Mode 2 deviates from the fp32
- * forward by about 5e-4 of the largest predicted motion (measured <= 7.6e-4 x max|motion| on weights trained by the reference's train(),
- * tools/fuzz_parity.py), so beyond that size the 1e-4 max-abs gate is no longer guaranteed: precision 1 holds it at any motion size (<= 6e-6).
- * The reference has no counterpart to either bit (it computes in fp32 throughout, model.py:283-295). */
-enum { AG_STATUS_NONFINITE = 1, AG_STATUS_FAST_ENVELOPE = 2 };
+/* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on this
+ * model left the range of its arithmetic.  In precision mode 2 that is (a) an activation of the fp16 edge stack beyond +-65504 — detected in
+ * the epilogue that produces it, whatever later layers make of the inf — or (b) a non-finite value reaching the per-edge table or a message
+ * sum; with finite inputs both mean a checkpoint with large activations: switch the model to precision 1 (fp32 range).  In every mode,
+ * non-finite inputs raise it through the message sums.  The reference has no counterpart (fp32 throughout, model.py:283-295).
+ * (Until r03 bit 1 flagged mode-2 forwards that predicted motions above 0.125, where that round's arithmetic could leave the 1e-4 gate; the
+ * r04 arithmetic has no such range and the bit is never set.) */
+enum { AG_STATUS_NONFINITE = 1 };
 int ag_model_status(ag_model *m, int *flags /*host*/, ag_stream_t stream);
 
 /* Upper bound on the edge count the builder can emit: B*N*(min(N,topk) + (connect_tools_all ? max_tools : 0)). */

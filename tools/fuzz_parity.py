@@ -1,7 +1,7 @@
 """Randomised whole-path parity sweep: edge builder (bit-exact) and one forward (1e-4 gate) against the CPU oracle over random materials, particle
 counts (1 .. 2500), batches, padded / randomly invalidated slots, per-sample physics parameters and tool actions, precision modes, node
 de-duplication on / off and seed-0 / trained weights.  Prints the worst deviation per precision mode and every failure; exit status 1 on any.
-A precision-mode-2 case whose status carries AG_STATUS_FAST_ENVELOPE (a predicted motion above 0.125) is held to 1e-3 of its largest motion instead.
+Every mode is held to the absolute gate at any motion size and must leave the model status at 0.
     python tools/fuzz_parity.py [cases=120] [seed=0] [precision: 0 / 1 / 2, default random per case]"""
 import os, sys
 import numpy as np, torch
@@ -41,7 +41,7 @@ def model(mat, wname, prec, dedup):
 worst = {0: 0.0, 1: 0.0, 2: 0.0}
 worst_rel = {0: 0.0, 1: 0.0, 2: 0.0}      # deviation / max(|reference motion|) of the case
 fails = 0
-flagged = 0
+max_mag = 0.0
 for case in gen_cases(cases, seed, only_prec):
     mat, g, prec, dedup, wname, variant, tag = (case[k] for k in ("mat", "g", "prec", "dedup", "wname", "variant", "tag"))
     mm = synth.MATERIALS[mat]
@@ -61,14 +61,11 @@ for case in gen_cases(cases, seed, only_prec):
     e = float(np.abs(mot.cpu().numpy() - ref_mot).max()); ep = float(np.abs(pos.cpu().numpy() - ref_pos).max())
     st = m.take_status()
     worst[prec] = max(worst[prec], e)
-    mag = float(np.abs(ref_mot).max())
+    mag = float(np.abs(ref_mot).max()); max_mag = max(max_mag, mag)
     worst_rel[prec] = max(worst_rel[prec], e / max(mag, 1e-3))
     if os.environ.get("FUZZ_VERBOSE"): print(f"{e:.3e} |motion| {mag:.3f} rel {e / max(mag, 1e-3):.2e}", tag)
-    # a fast-mode forward outside its validated motion range says so (AG_STATUS_FAST_ENVELOPE) and is then held to 1e-3 of the largest motion
-    flagged += (st & 2) != 0
-    gate = max(GATE, 1e-3 * mag) if st & 2 else GATE
-    if not (e <= gate and ep <= gate and (st & ~2) == 0 and (prec == 2 or st == 0)):
+    if not (e <= GATE and ep <= GATE and st == 0):
         fails += 1; print(f"FORWARD {e:.3e} / {ep:.3e} status {st} (max |reference motion| {mag:.3f})", tag)
-print(f"{cases} cases, {fails} failures, {flagged} outside the fast mode's motion envelope (status bit 1); worst motion deviation per precision mode (f32, bf16x3, fast): "
+print(f"{cases} cases, {fails} failures; largest reference motion {max_mag:.3f}; worst motion deviation per precision mode (f32, bf16x3, fast): "
       f"{worst[0]:.2e} {worst[1]:.2e} {worst[2]:.2e}; relative to the case's max |motion|: {worst_rel[0]:.2e} {worst_rel[1]:.2e} {worst_rel[2]:.2e}")
 sys.exit(1 if fails else 0)

@@ -24,7 +24,8 @@ def csr(n_rel, recv, send, N):
     return CSREdges(t(row_ptr), t(pad(r)), t(pad(s)), B, N, len(r))
 
 
-for prec in (0, 1, 2):
+if __name__ == "__main__":
+  for prec in (0, 1, 2):
     worst = 0.0
     for name in golden_files("fwd_"):
         g = load_golden(name)
