@@ -68,6 +68,25 @@ void f16_split(float v, uint16_t &hi, uint16_t &lo)
     memcpy(&hi, &h, 2);
     memcpy(&lo, &l, 2);
 }
+// OCP e4m3fn (1-4-3, bias 7, subnormals, max 448, no inf), round-to-nearest-even, saturating: the A-operand format of the block-scaled MFMA
+uint8_t e4m3_rne(float v)
+{
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+    const float a = fabsf(v);
+    if (!(a > 0.0f)) return sign;
+    if (a >= 448.0f) return sign | 0x7e;
+    int e;
+    (void)frexpf(a, &e);
+    e -= 1;                                            // a = f * 2^e, f in [1, 2)
+    if (e < -6) {                                      // subnormal: multiples of 2^-9 (8 of them reach the smallest normal, whose pattern is 8)
+        return sign | (uint8_t)nearbyintf(ldexpf(a, 9));
+    }
+    int m = (int)nearbyintf((ldexpf(a, -e) - 1.0f) * 8.0f);
+    if (m == 8) { m = 0; e += 1; }
+    const int bits = ((e + 7) << 3) | m;
+    return sign | (uint8_t)(bits > 0x7e ? 0x7e : bits);
+}
+
 float bf16_to_f32(uint16_t b)
 {
     const uint32_t u = (uint32_t)b << 16;
@@ -142,6 +161,67 @@ void pack_layer(std::vector<float> &dst, int b3, const float *W, int ld, int col
     }
 }
 
+// One wide layer of the fp16 edge stack (PrecH3, ag_mlp.hip) as n_tiles chunk images of 20 480 bytes + their block scales:
+//   bytes [0, 10240):      hi = fp16(W) fragments, [10 k16-steps u][64 lanes (i, h)][8 fp16], slot e = column 16u + 8(e>>2) + 4h + (e&3)
+//   bytes [10240, 20480):  the A operands of the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), [5 input tiles t][64 lanes (i, h)][32 B]:
+//                          bytes 0..15 = e4m3(W_lo / s_lo), bytes 16..31 = e4m3(W_hi / s_hi) of columns 32t + 8q + 4h + p at byte 4q + p
+//                          (W_lo = W - hi; the instruction pairs byte k of an A lane with byte k of the B lane of the same half, and the two
+//                          16-byte groups are its two K blocks: the kernels put [top byte of x16 | e5m2(x - x16)] of the same columns there)
+//   scales (appended to `scales`, 128 dwords per tile): [2 dwords][64 lanes]: lane (i, h) holds the E8M0 exponents of its row's five input tiles,
+//                          h = 0: s_lo, h = 1: s_hi (a K block takes its A scale from the lanes of the half with the block's number):
+//                          dword 0 = tiles 0..3 (one byte each, selected by op_sel), dword 1 byte 0 = tile 4.  s = 2^(floor(log2(block max)) - 7).
+void pack_layer_h3(std::vector<float> &dst, std::vector<uint32_t> &scales, const float *W, int ld, int col0, int K, int n_out, const float *bias,
+                   int n_tiles)
+{
+    for (int ti = 0; ti < n_tiles; ++ti) {
+        const size_t base = dst.size();
+        dst.resize(base + AG_CHUNK_FLOATS, 0.0f);
+        uint16_t *hi16 = reinterpret_cast<uint16_t *>(dst.data() + base);
+        uint8_t *mx = reinterpret_cast<uint8_t *>(dst.data() + base) + 10240;
+        const size_t sbase = scales.size();
+        scales.resize(sbase + 128, 0x7f7f7f7fu);
+        for (int i = 0; i < 32; ++i) {
+            const int o = 32 * ti + i;
+            float w[AG_FP], lo[AG_FP], hif[AG_FP];
+            for (int k = 0; k < AG_FP; ++k) {
+                w[k] = 0.0f;
+                if (o < n_out) w[k] = k < K ? W[(size_t)o * ld + col0 + k] : ((k == K && bias) ? bias[o] : 0.0f);
+                uint16_t hb, lb;
+                f16_split(w[k], hb, lb);
+                const _Float16 hh = (_Float16)w[k];
+                hif[k] = (float)hh;
+                lo[k] = w[k] - hif[k];
+                const int u = k >> 4, r = k & 15, h = (r >> 2) & 1, e = (r >> 3) * 4 + (r & 3), lane = h * 32 + i;
+                hi16[((size_t)u * 64 + lane) * 8 + e] = hb;
+            }
+            for (int t = 0; t < AG_NT; ++t) {
+                float mlo = 0.0f, mhi = 0.0f;
+                for (int k = 32 * t; k < 32 * t + 32; ++k) { mlo = fmaxf(mlo, fabsf(lo[k])); mhi = fmaxf(mhi, fabsf(hif[k])); }
+                auto expo = [](float m) {      // E8M0 byte of 2^(floor(log2 m) - 7): the block maximum lands in [128, 256) <= 448
+                    int e = 0;
+                    (void)frexpf(m, &e);
+                    const int b = (e - 1) - 7 + 127;
+                    return b < 1 ? 1 : (b > 254 ? 254 : b);
+                };
+                const int elo = mlo > 0.0f ? expo(mlo) : 127, ehi = mhi > 0.0f ? expo(mhi) : 127;
+                for (int h = 0; h < 2; ++h) {
+                    const int lane = h * 32 + i;
+                    uint32_t &word = scales[sbase + (t >> 2) * 64 + lane];
+                    const uint32_t byte = (uint32_t)(h ? ehi : elo);
+                    word = (word & ~(0xffu << (8 * (t & 3)))) | (byte << (8 * (t & 3)));
+                    for (int q = 0; q < 4; ++q)
+                        for (int pp = 0; pp < 4; ++pp) {
+                            const int k = 32 * t + 8 * q + 4 * h + pp;
+                            uint8_t *dstb = mx + ((size_t)t * 64 + lane) * 32 + 4 * q + pp;
+                            dstb[0] = e4m3_rne(ldexpf(lo[k], 127 - elo));
+                            dstb[16] = e4m3_rne(ldexpf(hif[k], 127 - ehi));
+                        }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 struct ag_model {
@@ -205,11 +285,15 @@ int pack_and_upload(ag_model *m, const float *const *t)
         pack_layer(s, b3, t[W_D1], F, 0, F, F, t[B_D1], AG_NT);
         pack_layer(s, b3, t[W_D2], F, 0, F, 3, t[B_D2], 1);
     }
-    const size_t off_h2 = s.size();                                        // edge_encode stream, split-fp16
+    const size_t off_h2 = s.size();                                        // edge_encode stream of the fp16 edge stack (PrecH3)
+    std::vector<uint32_t> sc;                                              // block scales of its 15 wide units, 128 dwords each
     pack_first_layer(s, 2, t[W_RE0], de, F, t[B_RE0], 2 * m->cfg.attr_dim + 1);      // + residual columns for the 12 state differences, inputs 5..16 (AG_EDGE_LO_FEAT0)
-    pack_layer(s, 2, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
-    pack_layer(s, 2, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
-    pack_layer(s, 2, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
+    pack_layer_h3(s, sc, t[W_RE1], F, 0, F, F, t[B_RE1], AG_NT);
+    pack_layer_h3(s, sc, t[W_RE2], F, 0, F, F, t[B_RE2], AG_NT);
+    pack_layer_h3(s, sc, t[W_RP], 3 * F, 0, F, F, t[B_RP], AG_NT);
+    const size_t off_sc = s.size();
+    s.resize(off_sc + sc.size());
+    memcpy(s.data() + off_sc, sc.data(), sc.size() * sizeof(uint32_t));
     if (!m->dev) {
         AG_HIP(hipMalloc(reinterpret_cast<void **>(&m->dev), s.size() * sizeof(float)));
         m->dev_floats = s.size();
@@ -237,6 +321,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
     m->w.node_encode = at(0, 0); m->w.edge_encode = at(0, 1); m->w.node_mid = at(0, 2); m->w.node_last = at(0, 3);
     m->w.node_encode_b3 = at(1, 0); m->w.edge_encode_b3 = at(1, 1); m->w.node_mid_b3 = at(1, 2); m->w.node_last_b3 = at(1, 3);
     m->w.edge_encode_h2 = reinterpret_cast<const float4 *>(m->dev + off_h2);
+    m->w.edge_scale_h3 = reinterpret_cast<const uint32_t *>(m->dev + off_sc);
     return AG_OK;
 }
 

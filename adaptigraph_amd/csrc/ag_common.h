@@ -46,8 +46,10 @@ struct AgWeights {           // device pointers into the packed weight streams (
     const float4 *node_last;     // PPb | D0 | D1 | D2(1 chunk)                 16 chunks
     // the same streams as split-bf16 fragment images (precision AG_PREC_B3)
     const float4 *node_encode_b3, *edge_encode_b3, *node_mid_b3, *node_last_b3;
-    // the edge stream as split-fp16 fragment images (same layout as the bf16 ones; precision mode 2, two-product edge stack)
+    // the edge stream of the fp16 edge stack (precision mode 2, PrecH3): chunk 0 = the first layer as a split-fp16 fragment image, chunks 1..15 =
+    // the wide units as [hi fp16 fragments | block-scaled fp8 A operands] (ag_api.hip pack_layer_h3), and their block scales (128 dwords per unit)
     const float4 *edge_encode_h2;
+    const uint32_t *edge_scale_h3;
 };
 
 struct AgFwdArgs {

@@ -94,6 +94,7 @@ struct ChunkPipe {
     int fetch;         // next stream chunk to fetch (wraps at total)
     int buf;           // LDS buffer holding the current chunk (0/1)
     float *lds;        // 2 * AG_CHUNK_FLOATS
+    const uint32_t *scales = nullptr;   // PrecH3 only: block scales of the stream's wide units (128 dwords per chunk after the first)
 };
 
 // Asynchronous global -> LDS copy of the next weight chunk (global_load_lds_dwordx4: LDS-DMA, no VGPR staging,
@@ -161,12 +162,22 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
 
 // ---- q16: the 16-bit per-edge table of precision mode 2 (format: ag_common.h).  The pieces below are shared by the streaming kernels'
 //      epilogue (RowStoreQ16Epi) and the weight-stationary kernel's micro-chores, so both write the same bits. ------------------------------
-// largest |v| of two values against a running maximum, on the BIT PATTERNS (|x| orders like an unsigned integer, and inf / NaN sort above
-// every finite value, so a non-finite accumulator ends up in the block exponent instead of vanishing in a float maximum)
+// largest |v| of two values against a running maximum (as a bit pattern; m >= 0).  NANSAFE: compared as unsigned integers — |x| orders
+// like one, and inf / NaN sort above every finite value, so a non-finite accumulator ends up in the block exponent and raises the
+// status bit (the split-bf16 edge stack has no other check).  Otherwise ONE v_max3_f32 with |.| source modifiers: a NaN is dropped, inf
+// is kept — the fp16 edge stack flags the activation that would produce a NaN here in the epilogue that made it (h3_pair).  Both
+// give the same maximum for finite tiles.  (Inline asm on accumulators: callers read them >= 4 MFMAs after their last write.)
+template <bool NANSAFE>
 __device__ __forceinline__ unsigned q16_max2(unsigned m, float a, float b)
 {
-    const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu;
-    return max(m, max(ua, ub));
+    if constexpr (NANSAFE) {
+        const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu;
+        return max(m, max(ua, ub));
+    } else {
+        unsigned r;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+        return r;
+    }
 }
 // block exponent of an out-tile from the lane's own maximum: the other half of the tile's rows sits in lane j + 32 (v_permlane32_swap)
 __device__ __forceinline__ int q16_tile_exp(unsigned m, bool &nonfinite)
@@ -179,10 +190,12 @@ __device__ __forceinline__ int q16_tile_exp(unsigned m, bool &nonfinite)
     return eb < AG_Q16_EB_MIN ? AG_Q16_EB_MIN : (eb > AG_Q16_EB_MAX ? AG_Q16_EB_MAX : eb);
 }
 __device__ __forceinline__ float q16_inv_scale(int eb) { return __uint_as_float((unsigned)(253 - eb) << 23); }      // 2^(126 - eb)
-__device__ __forceinline__ unsigned q16_pack(float a, float b, float inv)          // two values -> packed snorm16 (round to nearest even)
+__device__ __forceinline__ unsigned q16_pack(float a, float b, float inv)          // two values -> packed snorm16 (round to nearest)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, (s16x2)__builtin_amdgcn_cvt_pknorm_i16(a * inv, b * inv));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = f32x2{a, b} * f32x2{inv, inv};                                 // v_pk_mul_f32
+    return __builtin_bit_cast(unsigned, (s16x2)__builtin_amdgcn_cvt_pknorm_i16(v[0], v[1]));
 }
 // stores of one out-tile of lane (j, h): `row` = table + e * 320 bytes; the lane's 32 bytes start at 64 ti + 32 h.  In tile 4 the last eight
 // bytes of the lane's chunk are padding that holds exponent bytes written by OTHER lanes / waves: they are not touched.
@@ -196,7 +209,10 @@ __device__ __forceinline__ void q16_store_half(unsigned char *row, int ti, int h
 }
 __device__ __forceinline__ void q16_store_exp(unsigned char *row, int ti, int h, int eb) { row[ag_q16_exp_byte_offset(ti, h)] = (unsigned char)eb; }
 
-struct RowStoreQ16Epi {     // Eterm as q16 (precision mode 2)
+struct RowStoreQ16Epi {     // Eterm as q16 (precision mode 2).  The maximum runs on compiler-visible integer instructions here: `v` comes straight
+                            // from builtin MFMAs, and an inline-asm reader gets no MFMA -> VALU wait states from the compiler (the asm version,
+                            // hoisted above the tile barrier, read accumulators the last scaled MFMA had not written yet: a block exponent off by
+                            // one in 1e-4 of the tiles).  Same result as the float maximum of the weight-stationary kernel for finite tiles.
     unsigned char *row;     // table + e * 320
     int h;
     int *status = nullptr;  // model status word: bit 0 is raised when a tile holds a non-finite value (or one beyond 2^127)
@@ -204,7 +220,7 @@ struct RowStoreQ16Epi {     // Eterm as q16 (precision mode 2)
     {
         unsigned m = 0;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) m = q16_max2(m, v[r], v[r + 1]);
+        for (int r = 0; r < 16; r += 2) m = q16_max2<true>(m, v[r], v[r + 1]);
         bool bad;
         const int eb = q16_tile_exp(m, bad);
         const float inv = q16_inv_scale(eb);
@@ -488,18 +504,21 @@ struct PrecB3 {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// H3 ("fp16 + e5m2 residual"): the arithmetic of the EDGE stack in precision mode 2.  Three fp16 MFMAs per k16-step:
-//   weight W = hi + lo, two fp16 (lo is mostly subnormal: the fp16 MFMA honours subnormal inputs on gfx950 —
-//   tools/ubench/mfma_f16_denorm.hip — so W carries >= 19 bits, absolute error <= 2^-25);
-//   activation x = x16 + r8:  x16 = fp16(x) (RNE, 11 significant bits),  r8 = e5m2(x - x16) (RNE, 3 significant bits: ONE byte,
-//   the top byte of the fp16 pattern of the residual, expanded to fp16 by a byte permute where it is consumed);
-//   acc += lo*x16; acc += hi*x16; acc += hi*r8   on v_mfma_f32_32x32x16_f16, fp32 accumulate.
-// History: r02-r03 ran the first two products only.  On weights trained by the reference the fp16 rounding of the
-// ACTIVATIONS (2^-12 relative, every layer of the stack contributing alike) then costs 2-5e-5 of the 1e-4 gate and grows with the
-// predicted motion (1.4e-4 at |motion| 0.2 in tools/fuzz_parity.py).  The residual byte removes 7/8 of it for 5 KB of LDS per layer
-// image instead of the 10 KB a second fp16 image would take (the weight-stationary kernel's LDS is full), at no extra weight registers
-// (the third product re-uses the hi fragments); float64 emulation on the fuzz cases (tools/scheme_err.py): 4.9e-5 -> 5.6e-6 together
-// with the q16 table, the level of the split-bf16 mode.
+// H3: the arithmetic of the EDGE stack in precision mode 2 — fp16 with byte-sized corrections on the block-scaled fp8 MFMA.
+//   weight      W = hi + lo:  hi = fp16(W);  the corrections use e4m3(lo / s_lo) and e4m3(hi / s_hi) with one power-of-two scale per
+//               (output row, 32-column input tile) (packed on the host: ag_api.hip pack_layer_h3)
+//   activation  x = x16 + r:  x16 = fp16(x) (RNE);  r8 = e5m2(x - x16) (RNE): ONE byte per value;  x8 = the top byte of x16 (= e5m2, truncated)
+//   per 32-column input tile t of an out-tile:
+//       acc += hi . x16   two v_mfma_f32_32x32x16_f16 (k16-steps 2t, 2t + 1)
+//       acc += s_lo (lo8 . x8) + s_hi (hi8 . r8)   ONE v_mfma_scale_f32_32x32x64_f8f6f4 (A e4m3, B e5m2; its two K blocks are the two terms)
+//   i.e. W.x = hi.x16 + lo.x16 + hi.r (+ lo.r ~ 2^-23, dropped) with the two 2^-11-sized terms at 3-4 significant bits.
+// History: r02-r03 ran hi.x16 + lo.x16 on twenty fp16 MFMAs per out-tile.  On weights trained by the reference the fp16 rounding of
+// the ACTIVATIONS (2^-12 relative, every layer contributing alike) then costs 2-5e-5 of the 1e-4 gate and grows with the predicted motion
+// (1.4e-4 at |motion| 0.2 in tools/fuzz_parity.py).  A third fp16 product hi.r fixes that (float64 emulation on the fuzz cases,
+// tools/scheme_err.py: 4.9e-5 -> 5.6e-6 with the q16 table) but the chip is POWER-limited under MFMA load (1 630 TFLOP/s of fp16 MFMA
+// sustained): thirty MFMAs per out-tile measured 0.91 ms for the edge encoder instead of 0.55.  The block-scaled instruction does K = 64 for
+// 1.25 fp16-MFMA-times (tools/ubench/mx_mfma.hip): ten fp16 MFMAs + five scaled ones = 16.25 MFMA-times per out-tile, LESS than the r03
+// scheme's 20, for the same 5.6e-6 -> 6.0e-6 emulated deviation.
 // RANGE: a hidden activation beyond +-65504 converts to +inf.  Every epilogue keeps the largest fp16 bit pattern it produced
 // (`bad`, one packed integer maximum per value pair) and raises status bit 0 when it reaches 0x7c00 (inf / NaN): the overflow is
 // reported WHERE it happens, whatever later layers make of it.  For checkpoints with larger activations use precision 1
@@ -508,7 +527,7 @@ struct PrecB3 {
 // FIRST layer of the edge stack: its 17 inputs + bias column use 18 of the 32 K slots of two k16-steps.  Twelve of the inputs are
 // position / velocity differences of any size (a tool joined to every cloth particle by connect_tools_all sits metres away: |x| ~ 50
 // rounds to fp16 with an error of 0.01).  Spare slots 18..29 carry the fp16 rounding residuals of inputs 5..16 against the same weight
-// columns (ag_api.hip pack_first_layer), so the first layer sees them to 2^-22 at no extra MFMA and needs no third product.
+// columns (ag_api.hip pack_first_layer), so the first layer sees them to 2^-22 on two plain fp16 products (split-fp16 weights).
 #define AG_EDGE_LO_SLOT0 (AG_EDGE_IN + 1)       // first residual slot
 #define AG_EDGE_LO_FEAT0 (2 * AG_ATTR + 1)      // first input with a residual: the state differences (model.py:241-253)
 #define AG_EDGE_LO_COUNT (AG_EDGE_IN - AG_EDGE_LO_FEAT0)
@@ -516,6 +535,8 @@ static_assert(AG_EDGE_LO_SLOT0 == 18 && AG_EDGE_LO_FEAT0 == 5 && AG_EDGE_LO_COUN
 __device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
 
 typedef unsigned h3_u32x4 __attribute__((ext_vector_type(4)));
+typedef int h3_i32x8 __attribute__((ext_vector_type(8)));
+#define AG_H3_HI_BYTES 10240      // a wide unit's chunk image: [0, 10240) fp16 hi fragments, [10240, 20480) the scaled MFMA's A operands
 // two (already ReLU'd) fp32 activations -> the packed fp16 pair and their two residual bytes (into the low or high half of R)
 template <bool SIGNED = false>      // SIGNED: the values may be negative (raw first-layer inputs): the range check then ignores the sign bits
 __device__ __forceinline__ unsigned h3_pair(float x0, float x1, int &R, bool hi_word, unsigned &bad)
@@ -527,19 +548,26 @@ __device__ __forceinline__ unsigned h3_pair(float x0, float x1, int &R, bool hi_
     const unsigned H = __builtin_bit_cast(unsigned, hx);
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     bad = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, bad), __builtin_bit_cast(u16x2, SIGNED ? (H & 0x7fff7fffu) : H)));
-    const float r0 = x0 - (float)hx[0], r1 = x1 - (float)hx[1];
+    // r = x - float(x16), exact: one v_fma_mix_f32 per value (fp16 source read in place; the compiler's own selection is convert + subtract)
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(H), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(H), "v"(x1));
     R = hi_word ? __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, R, true) : __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, R, false);
     return H;
 }
-// eight residual bytes (R[0] = elements 0..3, R[1] = 4..7) -> eight fp16: byte b becomes the half-word b << 8 (e5m2 IS the top byte of fp16)
-__device__ __forceinline__ h3_u32x4 h3_expand(int R0, int R1)
+// x8 of an input tile: the top bytes of the sixteen fp16 values of k16-steps 2t (xa) and 2t + 1 (xb), in element order
+__device__ __forceinline__ h3_u32x4 h3_top_bytes(const h3_u32x4 &xa, const h3_u32x4 &xb)
 {
     h3_u32x4 r;
-    r[0] = __builtin_amdgcn_perm((unsigned)R0, (unsigned)R0, 0x010c000cu);
-    r[1] = __builtin_amdgcn_perm((unsigned)R0, (unsigned)R0, 0x030c020cu);
-    r[2] = __builtin_amdgcn_perm((unsigned)R1, (unsigned)R1, 0x010c000cu);
-    r[3] = __builtin_amdgcn_perm((unsigned)R1, (unsigned)R1, 0x030c020cu);
+    r[0] = __builtin_amdgcn_perm(xa[1], xa[0], 0x07050301u);
+    r[1] = __builtin_amdgcn_perm(xa[3], xa[2], 0x07050301u);
+    r[2] = __builtin_amdgcn_perm(xb[1], xb[0], 0x07050301u);
+    r[3] = __builtin_amdgcn_perm(xb[3], xb[2], 0x07050301u);
     return r;
+}
+__device__ __forceinline__ h3_i32x8 h3_b_operand(const h3_u32x4 &x8, const h3_u32x4 &r8)
+{
+    return h3_i32x8{(int)x8[0], (int)x8[1], (int)x8[2], (int)x8[3], (int)r8[0], (int)r8[1], (int)r8[2], (int)r8[3]};
 }
 // status bit 0 when a lane produced an fp16 inf / NaN (bit patterns >= 0x7c00 in either half-word of `bad`)
 __device__ __forceinline__ void h3_report(unsigned bad, int *status)
@@ -548,7 +576,7 @@ __device__ __forceinline__ void h3_report(unsigned bad, int *status)
 }
 
 struct PrecH3 {
-    struct Act { f16x8 v[2 * AG_NT], r[2 * AG_NT]; unsigned bad = 0; };
+    struct Act { f16x8 v[2 * AG_NT]; h3_u32x4 r8[AG_NT]; unsigned bad = 0; };      // fp16 values by k16-step, residual bytes by input tile
     __device__ __forceinline__ static void set_tile(Act &a, int ti, const f32x16 &v)
     {
 #pragma unroll
@@ -558,17 +586,16 @@ struct PrecH3 {
 #pragma unroll
             for (int w = 0; w < 4; ++w) H[w] = h3_pair<true>(v[8 * s + 2 * w], v[8 * s + 2 * w + 1], R[w >> 1], (w & 1) != 0, a.bad);
             a.v[2 * ti + s] = __builtin_bit_cast(f16x8, H);
-            a.r[2 * ti + s] = __builtin_bit_cast(f16x8, h3_expand(R[0], R[1]));
+            a.r8[ti][2 * s] = (unsigned)R[0];
+            a.r8[ti][2 * s + 1] = (unsigned)R[1];
         }
     }
 
-    // same tile loop as PrecB3::layer (weight ring, fragment prefetch, deferred epilogue), three MFMAs per k16-step
+    // tile loop as PrecB3::layer (weight ring, deferred epilogue); per input tile two fp16 MFMAs and one block-scaled fp8 MFMA
     template <int K, int NT, bool RELU, bool BIAS, class Init, class Epi, class Sink>
     __device__ __forceinline__ static void layer(ChunkPipe &P, const Act &in, const Init &init, const Epi &epi, Sink &&sink)
     {
-        constexpr int KE = K + (BIAS ? 1 : 0);
-        constexpr int NU = (KE + 15) / 16;
-        constexpr int PF = 2;
+        static_assert(K == AG_F && BIAS, "the scaled-MFMA images are packed for 150 inputs + the bias column");
         const int lane = threadIdx.x & 63, h = lane >> 5;
         f32x16 prev;
         auto finish = [&](int ti, f32x16 &v) {
@@ -582,32 +609,37 @@ struct PrecH3 {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+            const unsigned lm = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + AG_H3_HI_BYTES + lane * 32);
+            const int cur = P.fetch == 0 ? P.total - 1 : P.fetch - 1;         // stream chunk in P.buf (chunk 0 is the first layer)
+            const unsigned sc0 = P.scales[(cur - 1) * 128 + lane], sc1 = P.scales[(cur - 1) * 128 + 64 + lane];
             pipe_dma(P, P.buf ^ 1);
             f32x16 acc = init(ti);
-            bf16x8 wq[PF + 1][2];
-            static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                lds_read16<(2 * u) * 1024>(wq[u][0], la);
-                lds_read16<(2 * u + 1) * 1024>(wq[u][1], la);
-            });
+            bf16x8 wq[2][4];          // per input tile: hi fragments of its two k16-steps, the scaled operand's two 16-byte halves
+            auto issue = [&](auto T) {
+                constexpr int t = decltype(T)::value;
+                lds_read16<(2 * t) * 1024>(wq[t & 1][0], la);
+                lds_read16<(2 * t + 1) * 1024>(wq[t & 1][1], la);
+                lds_read16<t * 2048>(wq[t & 1][2], lm);
+                lds_read16<t * 2048 + 16>(wq[t & 1][3], lm);
+            };
+            issue(std::integral_constant<int, 0>{});
             if (ti > 0) finish(ti - 1, prev);
-            static_for<0, NU>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                if constexpr (u + PF < NU) {
-                    lds_read16<(2 * (u + PF)) * 1024>(wq[(u + PF) % (PF + 1)][0], la);
-                    lds_read16<(2 * (u + PF) + 1) * 1024>(wq[(u + PF) % (PF + 1)][1], la);
+            static_for<0, AG_NT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                if constexpr (t + 1 < AG_NT) issue(std::integral_constant<int, t + 1>{});
+                lds_wait_pair<(t + 1 < AG_NT ? 4 : 0)>(wq[t & 1][0], wq[t & 1][1]);
+                lds_wait_pair<(t + 1 < AG_NT ? 4 : 0)>(wq[t & 1][2], wq[t & 1][3]);
+                f16x8 xa = in.v[2 * t], xb = in.v[2 * t + 1];
+                if constexpr (K / 32 == t) {        // bias column: feature K = 16u + 8(e>>2) + 4h + (e&3) := 1.0 (its residual byte is 0: the feature is padding)
+                    constexpr int u = K / 16, o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
+                    if (h == hb) { if constexpr (u & 1) xb[e] = (_Float16)1.0f; else xa[e] = (_Float16)1.0f; }
                 }
-                constexpr int ahead = (NU - 1 - u) < PF ? (NU - 1 - u) : PF;
-                lds_wait_pair<2 * ahead>(wq[u % (PF + 1)][0], wq[u % (PF + 1)][1]);
-                const f16x8 wh = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][0]), wl = __builtin_bit_cast(f16x8, wq[u % (PF + 1)][1]);
-                f16x8 x = in.v[u];
-                if constexpr (BIAS && K / 16 == u) {        // feature K = 16u + 8(e>>2) + 4h + (e&3); its residual byte is 0 (the feature itself is padding)
-                    constexpr int o = K % 16, e = (o >> 3) * 4 + (o & 3), hb = (o >> 2) & 1;
-                    if (h == hb) x[e] = (_Float16)1.0f;
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, in.r[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[t & 1][0]), xa, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wq[t & 1][1]), xb, acc, 0, 0, 0);
+                const h3_u32x4 a0 = __builtin_bit_cast(h3_u32x4, wq[t & 1][2]), a1 = __builtin_bit_cast(h3_u32x4, wq[t & 1][3]);
+                const h3_i32x8 A = h3_b_operand(a0, a1);
+                const h3_i32x8 B = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa), __builtin_bit_cast(h3_u32x4, xb)), in.r8[t]);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 0, 1, t & 3, (int)(t < 4 ? sc0 : sc1), 0, 0x7f7f7f7f);
             });
             prev = acc;
             pipe_wait();
@@ -617,7 +649,7 @@ struct PrecH3 {
         finish(NT - 1, prev);
     }
 
-    // narrow first layer: two products (its inputs carry their own residuals in spare K slots, see above)
+    // narrow first layer: two plain fp16 products on split-fp16 weights (its inputs carry their own residuals in spare K slots, see above)
     template <int K, class Sink>
     __device__ __forceinline__ static void layer_first(ChunkPipe &P, const Act &in, Sink &&sink)
     {
@@ -898,7 +930,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
-    ChunkPipe P{edge_stream<Prec>(w), 16, 0, 0, lds};
+    ChunkPipe P{edge_stream<Prec>(w), 16, 0, 0, lds, w.edge_scale_h3};
     pipe_start(P);
     TileQueue q(a.tile_ctr, s_next_tile);   // ~38 row tiles per workgroup at C2
 #pragma unroll 1
@@ -1073,45 +1105,43 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 #define AG_WS_LAG_2 6
 #define AG_WS_LAG_3 8
 
-typedef f16x8 WsUnit[10][2];     // A-operand fragments of one (layer, out-tile) unit: [k16-step][hi | lo]
+// A (layer, out-tile) unit's A operands: fp16 hi fragments by k16-step, the block-scaled MFMA's operands [e4m3 lo | e4m3 hi] by input tile, and
+// the unit's block scales (lane (i, h): h = 0 the lo scales, h = 1 the hi scales; sc0 = tiles 0..3 by byte, sc1 byte 0 = tile 4)
+struct WsUnit { f16x8 hi[10]; h3_i32x8 mx[AG_NT]; unsigned sc0, sc1; };
 typedef h3_u32x4 ws_u32x4;
 typedef int ws_i32x2 __attribute__((ext_vector_type(2)));
 
 // ACC: keep the unit in the accumulation-register half of the file; a wave holds three units (240 registers) there.
 template <bool ACC>
-__device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, int lane)
+__device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, const uint32_t *scales, int lane)
 {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int u = 0; u < 10; ++u)
+    for (int u = 0; u < 10; ++u) W.hi[u] = *reinterpret_cast<const f16x8 *>(chunk + u * 64 + lane);
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) W[u][hl] = *reinterpret_cast<const f16x8 *>(chunk + (2 * u + hl) * 64 + lane);
+    for (int t = 0; t < AG_NT; ++t) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(chunk + AG_H3_HI_BYTES / 16 + (t * 64 + lane) * 2);
+        const i32x4 b = *reinterpret_cast<const i32x4 *>(chunk + AG_H3_HI_BYTES / 16 + (t * 64 + lane) * 2 + 1);
+        W.mx[t] = h3_i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
+    W.sc0 = scales[lane];
+    W.sc1 = scales[64 + lane];
+    // opaque values (after ALL the loads: the asm is a use, and a use waits for its load): they must live in registers and cannot be re-loaded
+    // inside the persistent loop
 #pragma unroll
-    for (int u = 0; u < 10; ++u)          // (after ALL the loads: the asm is a use, and a use waits for its load)
+    for (int u = 0; u < 10; ++u) { if (ACC) asm volatile("" : "+a"(W.hi[u])); else asm volatile("" : "+v"(W.hi[u])); }
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-            // an opaque value: it must live in a register and cannot be re-loaded inside the persistent loop
-            if (ACC) asm volatile("" : "+a"(W[u][hl]));
-            else asm volatile("" : "+v"(W[u][hl]));
-        }
+    for (int t = 0; t < AG_NT; ++t) { if (ACC) asm volatile("" : "+a"(W.mx[t])); else asm volatile("" : "+v"(W.mx[t])); }
+    asm volatile("" : "+v"(W.sc0), "+v"(W.sc1));
 }
-template <int OFF>
-__device__ __forceinline__ void lds_read8(ws_i32x2 &d, unsigned lds_byte_addr)
-{
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_byte_addr), "n"(OFF));
-}
+__device__ __forceinline__ unsigned lds_addr3(const __attribute__((address_space(3))) void *p) { return (unsigned)(uintptr_t)p; }
 template <int N>
 __device__ __forceinline__ void ws_wait2(bf16x8 &a, bf16x8 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 template <int N>
-__device__ __forceinline__ void ws_wait_xr(bf16x8 &x, ws_i32x2 &r)
+__device__ __forceinline__ void ws_wait3(bf16x8 &a, bf16x8 &b, bf16x8 &c)
 {
     static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(r) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void ws_wait_xr2(bf16x8 &x0, ws_i32x2 &r0, bf16x8 &x1, ws_i32x2 &r1)
-{
-    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x0), "+v"(r0), "+v"(x1), "+v"(r1) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
 }
 
 // acc (+)= W . x from inline asm: accumulator and B operand in architectural registers, A operand where the unit lives
@@ -1126,81 +1156,113 @@ __device__ __forceinline__ void ws_mfma(f32x16 &acc, const f16x8 &w, const bf16x
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
     }
 }
+// acc += 2^(sa - 127) 2^(sb - 127) A8 . B8 over two 32-element K blocks: A e4m3 (cbsz 0), B e5m2 (blgp 1); the A scale is byte SEL of `sa` in the
+// lanes of the half with the block's number, the B scale byte 0 of `sb`
+template <bool ACC, int SEL>
+__device__ __forceinline__ void ws_mfma_mx(f32x16 &acc, const h3_i32x8 &a, const h3_i32x8 &b, unsigned sa, unsigned sb)
+{
+#define AG_MX(OPS) \
+    do { if constexpr (ACC) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "a"(a), "v"(b), "v"(sa), "v"(sb)); \
+         else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb)); } while (0)
+    if constexpr (SEL == 0) AG_MX("op_sel:[0,0,0] op_sel_hi:[0,0,0]");
+    else if constexpr (SEL == 1) AG_MX("op_sel:[1,0,0] op_sel_hi:[0,0,0]");
+    else if constexpr (SEL == 2) AG_MX("op_sel:[0,0,0] op_sel_hi:[1,0,0]");
+    else AG_MX("op_sel:[1,0,0] op_sel_hi:[1,0,0]");
+#undef AG_MX
+}
 
-// operand rings of a wave: per input image a three-deep ring of fp16 fragments (16 bytes per lane and k16-step) and of residual bytes (8)
+// operand rings of a wave, two input tiles deep: per input set the fp16 fragments of the tile's two k16-steps and its sixteen residual bytes
 struct WsRing {
-    bf16x8 q0[3], q1[3];
-    ws_i32x2 r0[3], r1[3];
-    unsigned lane8;              // lane * 8: the residual image of a set starts AG_WS_IMG bytes after the fp16 image, 8 bytes per lane
-    __device__ __forceinline__ unsigned res(unsigned la) const { return la + AG_WS_IMG - lane8; }      // la = set + lane * 16
+    bf16x8 xa0[2], xb0[2], r0[2];
+    bf16x8 xa1[2], xb1[2], r1[2];
 };
 
-// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input set at LDS address la0, accumulators
-// [NA0, NA0 + NA1) the following units on the set at la1; units with index < NACC live in accumulation registers.
-// An accumulator's three MFMAs of a k16-step (lo.x, hi.x, hi.r) are issued BACK TO BACK with nothing in between (the dependent MFMA
-// then uses the pipe's accumulate path; one MFMA of another chain in between leaves it waiting for the write-back: s_memtime,
-// 40 cycles per MFMA instead of 32), and the next triple on the same accumulator follows >= 3 MFMAs later.
-// slot(IC<p>) runs after triple p = u * NA + k (p = 0 .. 10 NA - 1).
-// With NEXT_NIN > 0 the phase also issues the first two k16-steps of the NEXT phase (NEXT_NIN input sets at na0 / na1) during its own
-// steps 8 and 9, and that phase is instantiated with PRE = true and the ring offset RO = 1 (its step s sits in ring slot
-// (s + RO) % 3): no exposed LDS round trip between phases.
+// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input set at LDS address la0 (this lane's 16 bytes of k16-step 0),
+// accumulators [NA0, NA0 + NA1) the following units on the set at la1; units with index < NACC live in accumulation registers.
+// Per input tile t (32 input columns) an accumulator gets hi.x16 of k16-steps 2t, 2t + 1 and the scaled correction product, issued BACK TO
+// BACK with nothing in between (the dependent MFMA then uses the pipe's accumulate path); the next triple on the same accumulator follows
+// >= 3 MFMAs later.  slot(IC<2p>), slot(IC<2p + 1>) run after triple p = t * NA + k (slot numbers 0 .. 10 NA - 1, in order).
+// With NEXT_NIN > 0 the phase also issues the reads of tile 0 of the NEXT phase (NEXT_NIN input sets at na0 / na1) during its own tile 4,
+// and that phase is instantiated with PRE = true and the ring offset RO = 1 (its tile t sits in ring slot (t + RO) % 2).
 template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, class Slot>
 __device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0 + NA1], WsRing &G, unsigned la0, unsigned la1,
                                          unsigned na0, unsigned na1, Slot &&slot)
 {
     constexpr int NIN = NA1 ? 2 : 1, NA = NA0 + NA1;
     static_assert(NA >= 2, "a lone accumulator chain would have every chore between its dependent MFMAs");
-    auto issue = [&](auto S) {
-        constexpr int s = decltype(S)::value;
-        if constexpr (s < 10) {
-            lds_read16<s * 1024>(G.q0[(s + RO) % 3], la0);
-            lds_read8<s * 512>(G.r0[(s + RO) % 3], G.res(la0));
+    auto issue = [&](auto TT) {
+        constexpr int t = decltype(TT)::value, ri = (t + RO) % 2;
+        if constexpr (t < AG_NT) {
+            lds_read16<(2 * t) * 1024>(G.xa0[ri], la0);
+            lds_read16<(2 * t + 1) * 1024>(G.xb0[ri], la0);
+            lds_read16<AG_WS_IMG + t * 1024>(G.r0[ri], la0);
             if constexpr (NA1 > 0) {
-                lds_read16<s * 1024>(G.q1[(s + RO) % 3], la1);
-                lds_read8<s * 512>(G.r1[(s + RO) % 3], G.res(la1));
+                lds_read16<(2 * t) * 1024>(G.xa1[ri], la1);
+                lds_read16<(2 * t + 1) * 1024>(G.xb1[ri], la1);
+                lds_read16<AG_WS_IMG + t * 1024>(G.r1[ri], la1);
             }
         } else if constexpr (NEXT_NIN > 0) {
-            lds_read16<(s - 10) * 1024>(G.q0[(s + RO) % 3], na0);
-            lds_read8<(s - 10) * 512>(G.r0[(s + RO) % 3], G.res(na0));
+            lds_read16<0>(G.xa0[ri], na0);
+            lds_read16<1024>(G.xb0[ri], na0);
+            lds_read16<AG_WS_IMG>(G.r0[ri], na0);
             if constexpr (NEXT_NIN > 1) {
-                lds_read16<(s - 10) * 1024>(G.q1[(s + RO) % 3], na1);
-                lds_read8<(s - 10) * 512>(G.r1[(s + RO) % 3], G.res(na1));
+                lds_read16<0>(G.xa1[ri], na1);
+                lds_read16<1024>(G.xb1[ri], na1);
+                lds_read16<AG_WS_IMG>(G.r1[ri], na1);
             }
         }
     };
-    if constexpr (!PRE) {
-        issue(std::integral_constant<int, 0>{});
-        issue(std::integral_constant<int, 1>{});
-    }
-    static_for<0, 10>([&](auto U) {
-        constexpr int u = decltype(U)::value, ri = (u + RO) % 3;
-        issue(std::integral_constant<int, u + 2>{});
-        constexpr int n1 = (u + 1 < 10) ? NIN : NEXT_NIN, n2 = (u + 2 < 10) ? NIN : NEXT_NIN;      // input sets whose (two) reads were issued after step u's
-        if constexpr (NA1 > 0) ws_wait_xr2<2 * (n1 + n2)>(G.q0[ri], G.r0[ri], G.q1[ri], G.r1[ri]); else ws_wait_xr<2 * (n1 + n2)>(G.q0[ri], G.r0[ri]);
-        const bf16x8 x0 = G.q0[ri], x1 = NA1 > 0 ? G.q1[ri] : G.q0[ri];
-        bf16x8 rx0 = __builtin_bit_cast(bf16x8, h3_expand(G.r0[ri][0], G.r0[ri][1]));
-        bf16x8 rx1 = rx0;
-        if constexpr (NA1 > 0) rx1 = __builtin_bit_cast(bf16x8, h3_expand(G.r1[ri][0], G.r1[ri][1]));
+    if constexpr (!PRE) issue(std::integral_constant<int, 0>{});
+    const unsigned one = 0x7f7f7f7fu;      // E8M0 127 = 2^0: the activations' bytes are plain e5m2 numbers
+    // The scaled MFMA reads its eight B registers over several passes AFTER it has issued: a permute that re-uses them for the next tile a
+    // dozen instructions later corrupted the residual half of the LAST accumulator's operand (found as a rare 3e-5 relative difference from the
+    // streaming kernel).  So the B operands alternate between two register sets by tile parity, each kept reserved until the end of the NEXT tile.
+    h3_i32x8 Bq0[2], Bq1[2];
+    static_for<0, AG_NT>([&](auto TT) {
+        constexpr int t = decltype(TT)::value, ri = (t + RO) % 2;
+        issue(std::integral_constant<int, t + 1>{});
+        constexpr int after = (t + 1 < AG_NT) ? NIN : NEXT_NIN;      // input sets whose (three) reads were issued after tile t's
+        ws_wait3<3 * after>(G.xa0[ri], G.xb0[ri], G.r0[ri]);
+        if constexpr (NA1 > 0) ws_wait3<3 * after>(G.xa1[ri], G.xb1[ri], G.r1[ri]);
+        const bf16x8 xa0 = G.xa0[ri], xb0 = G.xb0[ri], xa1 = NA1 > 0 ? G.xa1[ri] : G.xa0[ri], xb1 = NA1 > 0 ? G.xb1[ri] : G.xb0[ri];
+        h3_i32x8 &B0 = Bq0[t & 1], &B1 = NA1 > 0 ? Bq1[t & 1] : Bq0[t & 1];
+        B0 = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa0), __builtin_bit_cast(h3_u32x4, xb0)), __builtin_bit_cast(h3_u32x4, G.r0[ri]));
+        if constexpr (NA1 > 0) B1 = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa1), __builtin_bit_cast(h3_u32x4, xb1)), __builtin_bit_cast(h3_u32x4, G.r1[ri]));
         // An MFMA that reads a register a VALU instruction has just written needs two wait states (the compiler inserts them for builtin
-        // MFMAs; the hazard recogniser does not look inside asm): the byte permutes are pinned here, ahead of the step's first MFMA.
-        if constexpr (NA1 > 0) asm volatile("s_nop 1" : "+v"(rx0), "+v"(rx1)); else asm volatile("s_nop 1" : "+v"(rx0));
+        // MFMAs; the hazard recogniser does not look inside asm): the byte permutes are pinned here, ahead of the tile's first MFMA.
+        if constexpr (NA1 > 0) asm volatile("s_nop 1" : "+v"(B0), "+v"(B1)); else asm volatile("s_nop 1" : "+v"(B0));
         static_for<0, NA>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            ws_mfma<(U0 + k < NACC), (u == 0)>(acc[k], W[U0 + k][u][1], k < NA0 ? x0 : x1);      // lo . x16
-            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? x0 : x1);         // hi . x16
-            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k][u][0], k < NA0 ? rx0 : rx1);       // hi . r8
-            slot(std::integral_constant<int, u * NA + k>{});
+            constexpr bool A = U0 + k < NACC;
+            const WsUnit &U = W[U0 + k];
+            // Placement (a lone wave issues in order: an instruction behind a dependent MFMA waits with it): the first chore runs in the
+            // shadow of the first fp16 MFMA (32 cycles), the second fp16 MFMA and the scaled one (which waits for it) follow back to
+            // back, the second chore runs in the shadow of the scaled MFMA (64 cycles); every piece is pinned.
+            ws_mfma<A, (t == 0)>(acc[k], U.hi[2 * t], k < NA0 ? xa0 : xa1);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(std::integral_constant<int, 2 * (t * NA + k)>{});
+            __builtin_amdgcn_sched_barrier(0);
+            ws_mfma<A, false>(acc[k], U.hi[2 * t + 1], k < NA0 ? xb0 : xb1);
+            ws_mfma_mx<A, (t & 3)>(acc[k], U.mx[t], k < NA0 ? B0 : B1, t < 4 ? U.sc0 : U.sc1, one);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(std::integral_constant<int, 2 * (t * NA + k) + 1>{});
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (t > 0) {      // the previous tile's operands are released only now
+            if constexpr (NA1 > 0) asm volatile("" :: "v"(Bq0[(t - 1) & 1]), "v"(Bq1[(t - 1) & 1])); else asm volatile("" :: "v"(Bq0[(t - 1) & 1]));
+        }
     });
+    if constexpr (NA1 > 0) asm volatile("" :: "v"(Bq0[(AG_NT - 1) & 1]), "v"(Bq1[(AG_NT - 1) & 1])); else asm volatile("" :: "v"(Bq0[(AG_NT - 1) & 1]));
 }
 
 // Epilogue micro-chores of the hidden layers.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values):
 // ReLU, packed fp16 convert, largest-pattern tracking, the two residual bytes (h3_pair); the fourth dword stores the consumer's 16 bytes
-// of k16-step 2T + S (bias column: feature 150 := 1.0) and its 8 residual bytes.
+// of k16-step 2T + S (bias column: feature 150 := 1.0) and its 8 residual bytes (residual image: [5 input tiles][64 lanes][16 bytes]).
 struct WsEpi { ws_u32x4 H; int R0, R1; unsigned bad; };
+typedef __attribute__((address_space(3))) unsigned char lds_u8;      // LDS pointers stay in their address space: a store is one ds_write with an
+                                                                     // immediate offset (through a generic pointer: two address instructions each)
 template <int T, int M>
-__device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, unsigned char *set_lane, unsigned lane8, int h)
+__device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, lds_u8 *set_lane, int h)
 {
     constexpr int S = M >> 2, w = M & 3;
     E.H[w] = h3_pair(relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1]), w < 2 ? E.R0 : E.R1, (w & 1) != 0, E.bad);
@@ -1208,8 +1270,8 @@ __device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, unsign
         if constexpr (T == 4 && S == 1) {           // feature 150 = 16*9 + 6: element e = 2 of the h = 1 half (its residual byte is 0: the feature is padding)
             if (h == 1) E.H[1] = (E.H[1] & 0xffff0000u) | 0x3c00u;
         }
-        *reinterpret_cast<ws_u32x4 *>(set_lane + (2 * T + S) * 1024) = E.H;
-        *reinterpret_cast<ws_i32x2 *>(set_lane + AG_WS_IMG - lane8 + (2 * T + S) * 512) = ws_i32x2{E.R0, E.R1};
+        *reinterpret_cast<__attribute__((address_space(3))) ws_u32x4 *>(set_lane + (2 * T + S) * 1024) = E.H;
+        *reinterpret_cast<__attribute__((address_space(3))) ws_i32x2 *>(set_lane + AG_WS_IMG + T * 1024 + S * 8) = ws_i32x2{E.R0, E.R1};
     }
 }
 // We: one out-tile of the q16 table in seven chores (format and helpers: RowStoreQ16Epi above): 0, 1 the lane's maximum over its 16 values,
@@ -1224,10 +1286,10 @@ __device__ __forceinline__ void ws_q16_chore(const f32x16 &acc, WsQ16 &Q, unsign
     if constexpr (C == 0) {
         Q.m = 0;
 #pragma unroll
-        for (int r = 0; r < 8; r += 2) Q.m = q16_max2(Q.m, acc[r], acc[r + 1]);
+        for (int r = 0; r < 8; r += 2) Q.m = q16_max2<false>(Q.m, acc[r], acc[r + 1]);
     } else if constexpr (C == 1) {
 #pragma unroll
-        for (int r = 8; r < 16; r += 2) Q.m = q16_max2(Q.m, acc[r], acc[r + 1]);
+        for (int r = 8; r < 16; r += 2) Q.m = q16_max2<false>(Q.m, acc[r], acc[r + 1]);
     } else if constexpr (C == 2) {
         bool nf;
         Q.eb = q16_tile_exp(Q.m, nf);
@@ -1283,7 +1345,6 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lane8 = lane * 8;
     const int Mn = a.B * a.N;
     const int E = a.row_ptr[Mn];
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
@@ -1300,8 +1361,8 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
     auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
     // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i
-    auto img = [&](int layer, int i) -> unsigned char * {
-        return layer == 0 ? &s_act0[(i + 12) % AG_WS_SLOTS0][lane * 16] : &s_act12[layer - 1][slot_of(i)][lane * 16];
+    auto img = [&](int layer, int i) -> lds_u8 * {
+        return (lds_u8 *)(layer == 0 ? &s_act0[(i + 12) % AG_WS_SLOTS0][lane * 16] : &s_act12[layer - 1][slot_of(i)][lane * 16]);
     };
     auto block_ok = [&](int i) { return i >= 0 && i < n_i; };
     auto eterm_row = [&](int i) {
@@ -1311,7 +1372,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     WsUnit W[4];
     WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
     WsRing G;
-    G.lane8 = lane8;
+    const uint32_t *wsc = w.edge_scale_h3;      // block scales of unit k (stream chunk 1 + k): wsc + 128 k
     // accumulators start at zero: the first rounds' chores convert them before any MFMA has written them
     auto zero = [](auto &arr) {
         for (auto &v : arr)
@@ -1322,7 +1383,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     if (wave == 0) {
         // ---------------------------------------------------------------- first layer, RE1 tiles 0-2
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + k) * AG_CHUNK_F4, lane);
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + k) * AG_CHUNK_F4, wsc + (size_t)((1 + k) - 1) * 128, lane);
         __syncthreads();
         f32x16 accF[5], accP[3];
         zero(accF); zero(accP);
@@ -1330,7 +1391,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i0 = r - AG_WS_LAG_F, i1 = r - AG_WS_LAG_1;
-            unsigned char *outF = img(0, i0), *outPp = img(1, i1 - 1);
+            lds_u8 *outF = img(0, i0), *outPp = img(1, i1 - 1);
             // first layer of block i0: 5 out-tiles x 2 k16-steps x (lo, hi), A fragments from LDS (five independent chains; two products:
             // the inputs carry their own residuals in spare K slots);  shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores in 20 slots)
             {
@@ -1352,25 +1413,25 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
                         ws_mfma<false, (g == 0)>(accF[t], __builtin_bit_cast(f16x8, fq[g & 1][t]), xq[u]);
                         constexpr int m = g * 5 + t;                           // 0..19
                         if constexpr (m < 4) {                                 // two micro-chores in the first four slots
-                            ws_act_micro<0, 2 * m>(accP[0], Ep, outPp, lane8, h);
-                            ws_act_micro<0, 2 * m + 1>(accP[0], Ep, outPp, lane8, h);
+                            ws_act_micro<0, 2 * m>(accP[0], Ep, outPp, h);
+                            ws_act_micro<0, 2 * m + 1>(accP[0], Ep, outPp, h);
                         } else {
                             constexpr int c = m + 4;                           // 8..23
-                            ws_act_micro<c / 8, c % 8>(accP[c / 8], Ep, outPp, lane8, h);
+                            ws_act_micro<c / 8, c % 8>(accP[c / 8], Ep, outPp, h);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             }
-            const unsigned la = lds_addr_of(img(0, i1));
+            const unsigned la = lds_addr3(img(0, i1));
             ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, G, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish the first layer (40 micro-chores in 30 slots)
                 constexpr int p = decltype(PP)::value;
                 if constexpr (p < 10) {
-                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], Ep, outF, lane8, h);
-                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], Ep, outF, lane8, h);
+                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], Ep, outF, h);
+                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], Ep, outF, h);
                 } else {
                     constexpr int c = p + 10;                           // 20..39
-                    ws_act_micro<c / 8, c % 8>(accF[c / 8], Ep, outF, lane8, h);
+                    ws_act_micro<c / 8, c % 8>(accF[c / 8], Ep, outF, h);
                 }
             });
             ws_round_barrier();
@@ -1378,9 +1439,9 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     } else if (wave == 1) {
         // ---------------------------------------------------------------- RE1 tiles 3-4, RE2 tiles 0-1, per-edge input gather
 #pragma unroll
-        for (int k = 0; k < 2; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + 3 + k) * AG_CHUNK_F4, lane);
-        ws_load_unit<true>(W[2], ws + (size_t)(6 + 0) * AG_CHUNK_F4, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(6 + 1) * AG_CHUNK_F4, lane);
+        for (int k = 0; k < 2; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + 3 + k) * AG_CHUNK_F4, wsc + (size_t)((1 + 3 + k) - 1) * 128, lane);
+        ws_load_unit<true>(W[2], ws + (size_t)(6 + 0) * AG_CHUNK_F4, wsc + (size_t)((6 + 0) - 1) * 128, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(6 + 1) * AG_CHUNK_F4, wsc + (size_t)((6 + 1) - 1) * 128, lane);
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
@@ -1401,11 +1462,11 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i1 = r - AG_WS_LAG_1, i2 = r - AG_WS_LAG_2;
-            const unsigned la1 = lds_addr_of(img(0, i1)), la2 = lds_addr_of(img(1, i2));
-            unsigned char *out1 = img(1, i1), *out2p = img(2, i2 - 1);
+            const unsigned la1 = lds_addr3(img(0, i1)), la2 = lds_addr3(img(1, i2));
+            lds_u8 *out1 = img(1, i1), *out2p = img(2, i2 - 1);
             ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la1, la1, la2, la2, [&](auto PP) {      // RE1 tiles 3, 4;  shadow: finish RE2 tiles 0, 1 of the previous block
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], Ep, out2p, lane8, h);
+                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], Ep, out2p, h);
                 // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1]
                 if constexpr (p == 14) {
                     feat[0] = R[0].x; feat[1] = R[0].y; feat[2] = S[0].x; feat[3] = S[0].y; feat[4] = fabsf(R[0].z - S[0].z); feat[AG_EDGE_IN] = 1.0f;
@@ -1439,7 +1500,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
             static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
             ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la2, la2, la2, la2, [&](auto PP) {      // RE2 tiles 0, 1;  shadow: finish RE1 tiles 3, 4
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], Ep, out1, lane8, h);
+                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], Ep, out1, h);
                 // node rows of block r - 1 (indices loaded last round): 2 x 64 bytes, one 16-byte load per piece
                 if constexpr (p >= 6 && p < 14) {
                     constexpr int q = (p - 6) & 3;
@@ -1458,8 +1519,8 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     } else if (wave == 2) {
         // ---------------------------------------------------------------- RE2 tiles 2-4, We tile 0
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(6 + 2 + k) * AG_CHUNK_F4, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(11 + 0) * AG_CHUNK_F4, lane);
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(6 + 2 + k) * AG_CHUNK_F4, wsc + (size_t)((6 + 2 + k) - 1) * 128, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(11 + 0) * AG_CHUNK_F4, wsc + (size_t)((11 + 0) - 1) * 128, lane);
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
@@ -1467,17 +1528,17 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i2 = r - AG_WS_LAG_2, i3 = r - AG_WS_LAG_3;
-            const unsigned la2 = lds_addr_of(img(1, i2)), la3 = lds_addr_of(img(2, i3));
-            unsigned char *out2 = img(2, i2), *out2p = img(2, i2 - 1);
+            const unsigned la2 = lds_addr3(img(1, i2)), la3 = lds_addr3(img(2, i3));
+            lds_u8 *out2 = img(2, i2), *out2p = img(2, i2 - 1);
             unsigned char *rowp = eterm_row(i3 - 1);
             ws_phase<0, 2, 0, 3, false, 0, 2>(W, accP, G, la2, la2, la2, la3, [&](auto PP) {      // RE2 tiles 2, 3;  shadow: finish RE2 tile 4 and We tile 0 of the previous blocks
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], Ep, out2p, lane8, h);
+                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], Ep, out2p, h);
                 if constexpr (p >= 8 && p < 15) ws_q16_chore<0, p - 8>(accQ[1], Q, rowp, h);
             });
             ws_phase<2, 1, 1, 3, true, 1, 0>(W, accQ, G, la2, la3, la2, la3, [&](auto PP) {      // RE2 tile 4 + We tile 0
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], Ep, out2, lane8, h);
+                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], Ep, out2, h);
             });
             ws_round_barrier();
         }
@@ -1485,8 +1546,8 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     } else {
         // ---------------------------------------------------------------- We tiles 1-4
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(11 + 1 + k) * AG_CHUNK_F4, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(11 + 4) * AG_CHUNK_F4, lane);
+        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(11 + 1 + k) * AG_CHUNK_F4, wsc + (size_t)((11 + 1 + k) - 1) * 128, lane);
+        ws_load_unit<false>(W[3], ws + (size_t)(11 + 4) * AG_CHUNK_F4, wsc + (size_t)((11 + 4) - 1) * 128, lane);
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
@@ -1494,7 +1555,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i3 = r - AG_WS_LAG_3;
-            const unsigned la3 = lds_addr_of(img(2, i3));
+            const unsigned la3 = lds_addr3(img(2, i3));
             unsigned char *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
             ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: store We tiles 3, 4 of the previous block
                 constexpr int p = decltype(PP)::value;

@@ -76,6 +76,23 @@ def q_bf8(v, pre):
     return torch.round(a / step) * step / 2.0 ** pre
 
 
+def q_e4m3_rows(w):
+    """weights -> OCP e4m3 with a power-of-two scale per (output row, 32-feature input tile): the block maximum lands in [128, 256)"""
+    n_out, K = w.shape
+    b = F.pad(w, (0, 160 - K)).reshape(n_out, 5, 32)
+    mx = b.abs().amax(-1, keepdim=True).clamp(min=1e-300)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) - 7)
+    a = (b / sc)
+    e = torch.floor(torch.log2(a.abs().clamp(min=1e-300))).clamp(min=-6)      # subnormals below 2^-6
+    step = torch.exp2(e - 3)
+    q = (torch.round(a / step) * step).clamp(-448, 448) * sc
+    return q.reshape(n_out, 160)[:, :K]
+
+
+def trunc_e5m2(x16):     # the top byte of the fp16 pattern (truncation)
+    return x16.half().view(torch.int16).bitwise_and(-256).view(torch.float16).double()
+
+
 def q_int_block(x, bits, block):
     """block fixed point: blocks of `block` consecutive features in accumulator order of one (tile, h); power-of-two scale from the block maximum"""
     Fdim = x.shape[-1]
@@ -125,6 +142,14 @@ class Scheme:
                 return F.linear(xe + q_bf8(x - xe, 0), w, b)
             r = (x - xe).half().view(torch.int16).bitwise_and(-256).view(torch.float16).double()
             return F.linear(xe + r, w, b)
+        if k == "h3x":           # W_hi16 . x16 on the fp16 MFMA + [e4m3(W_lo) | e4m3(W_hi)] . [top byte of x16 | e5m2(x - x16)] on the block-scaled fp8 MFMA
+            xe = h16(x)
+            if layer == 0:
+                xe[:, -12:] = xe[:, -12:] + h16(x[:, -12:] - xe[:, -12:])
+                return F.linear(xe, w, b)
+            wh = h16(w)
+            x8 = trunc_e5m2(xe) if self.res_cols != 98 else q_bf8(xe, 0)
+            return F.linear(xe, wh, b) + F.linear(x8, q_e4m3_rows(w - wh)) + F.linear(q_bf8(x - xe, 0), q_e4m3_rows(wh))
         if k == "x16x2r12":      # three fp16 products, layer 0 with residual slots for all 12 state inputs
             if layer == 0:
                 xe = h16(x); xe[:, -12:] = xe[:, -12:] + h16(x[:, -12:] - xe[:, -12:])
@@ -177,9 +202,9 @@ def forward(W, g, n_rel, recv, send, sch):
 SCHEMES = [
     Scheme("M2 (shipped r03: x fp16 + fp16 table)", "x16", h16),
     Scheme("exact stack + snorm16 per tile", "exact", q_int_tile),
-    Scheme("x16 + top-byte residual (3rd fp16 product) + snorm16/tile", "x16+r8t", q_int_tile),
     Scheme("x16 + e5m2(RNE) residual (3rd fp16 product) + snorm16/tile", "x16+r8t", q_int_tile, res_cols=99),
-    Scheme("x16 + e5m2(RNE) residual (3rd fp16 product) + fp16 table", "x16+r8t", h16, res_cols=99),
+    Scheme("H3X: hi16.x16 + MX fp8 [lo|hi].[x8 trunc|r8] + snorm16/tile", "h3x", q_int_tile),
+    Scheme("H3X with x8 rounded (RNE)", "h3x", q_int_tile, res_cols=98),
 ]
 
 if __name__ == "__main__":
