@@ -1075,8 +1075,11 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 //    of one 32-feature out-tile (30 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
 //    110-120 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
 //    the whole launch — 300 KB of the CU's 512 KB register file hold the entire edge stack:
-//        wave 0: first layer (its 20 KB of fragments in LDS), RE1 tiles 0-2      wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
-//        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: We tiles 1-4
+//        wave 0: first-layer tiles 0-2 (fragments in LDS), RE1 tiles 0-2         wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
+//        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: first-layer tiles 3-4, We tiles 1-4
+//    (the round is set by the wave with the most EPILOGUE work, not by matrix-pipe time — tools/trace_ws.py: with all five first-layer tiles on
+//    one wave that wave needed 5 100 of a 5 900-cycle round while the others waited 650-1 050 cycles at the barrier — so the first layer's
+//    epilogues are split 3 : 2 between the wave with three hidden tiles and the wave with the four cheap table tiles)
 //    Three units of a wave sit in the accumulation half of the register file (the MFMA reads its A operand from there
 //    directly), the fourth and all accumulators in the architectural half (the epilogue's VALU instructions read them directly).
 //  * 32-edge blocks flow through the waves as a software pipeline; a layer's 160 x 32 activation block is handed over through LDS
@@ -1231,20 +1234,26 @@ __device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0
         // An MFMA that reads a register a VALU instruction has just written needs two wait states (the compiler inserts them for builtin
         // MFMAs; the hazard recogniser does not look inside asm): the byte permutes are pinned here, ahead of the tile's first MFMA.
         if constexpr (NA1 > 0) asm volatile("s_nop 1" : "+v"(B0), "+v"(B1)); else asm volatile("s_nop 1" : "+v"(B0));
+        // Issue order (measured with the round trace, tools/trace_ws.py: a lone wave issues in order, a dependent MFMA waits for its
+        // predecessor's write-back — ~50 cycles after an fp16 MFMA, ~80 after a scaled one — and a lone chore is one dependent VALU chain of
+        // ~70 cycles): the fp16 MFMAs of ALL accumulators first, chain by chain interleaved, so that no MFMA waits for the one issued just
+        // before it; then one scaled MFMA per accumulator with TWO chores behind it — two independent VALU chains the compiler interleaves
+        // inside the scaled MFMA's 64-cycle shadow.  Triple-by-triple issue measured 208 cycles per triple, pipe time 128.
         static_for<0, NA>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            constexpr bool A = U0 + k < NACC;
+            ws_mfma<(U0 + k < NACC), (t == 0)>(acc[k], W[U0 + k].hi[2 * t], k < NA0 ? xa0 : xa1);
+        });
+        static_for<0, NA>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k].hi[2 * t + 1], k < NA0 ? xb0 : xb1);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NA>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
             const WsUnit &U = W[U0 + k];
-            // Placement (a lone wave issues in order: an instruction behind a dependent MFMA waits with it): the first chore runs in the
-            // shadow of the first fp16 MFMA (32 cycles), the second fp16 MFMA and the scaled one (which waits for it) follow back to
-            // back, the second chore runs in the shadow of the scaled MFMA (64 cycles); every piece is pinned.
-            ws_mfma<A, (t == 0)>(acc[k], U.hi[2 * t], k < NA0 ? xa0 : xa1);
+            ws_mfma_mx<(U0 + k < NACC), (t & 3)>(acc[k], U.mx[t], k < NA0 ? B0 : B1, t < 4 ? U.sc0 : U.sc1, one);
             __builtin_amdgcn_sched_barrier(0);
             slot(std::integral_constant<int, 2 * (t * NA + k)>{});
-            __builtin_amdgcn_sched_barrier(0);
-            ws_mfma<A, false>(acc[k], U.hi[2 * t + 1], k < NA0 ? xb0 : xb1);
-            ws_mfma_mx<A, (t & 3)>(acc[k], U.mx[t], k < NA0 ? B0 : B1, t < 4 ? U.sc0 : U.sc1, one);
-            __builtin_amdgcn_sched_barrier(0);
             slot(std::integral_constant<int, 2 * (t * NA + k) + 1>{});
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1337,6 +1346,34 @@ __global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a)
     for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
+// First layer of one 32-edge block for out-tiles [T0, T0 + NT): per tile 2 k16-steps x (lo, hi) fp16 MFMAs with the A fragments read from the
+// LDS image `wf` (this lane's 16 bytes of fragment 0; [5 tiles][2 steps][hi | lo][64 lanes][8 fp16]) and the block's input image at `lin` — NT
+// independent chains, two plain products (the inputs carry their own residuals in spare K slots).  slot(IC<m>) runs after MFMA m = g * NT + t
+// (g = 0..3: (step 0, lo), (step 0, hi), (step 1, lo), (step 1, hi)), m = 0 .. 4 NT - 1.
+template <int T0, int NT, class Slot>
+__device__ __forceinline__ void ws_first_layer(f32x16 (&accF)[NT], unsigned lin, unsigned wf, Slot &&slot)
+{
+    bf16x8 xq[2], fq[2][NT];
+    lds_read16<0>(xq[0], lin);
+    lds_read16<1024>(xq[1], lin);
+    static_for<0, NT>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<(((T0 + t) * 2 + 0) * 2 + 1) * 1024>(fq[0][t], wf); });
+    static_for<0, 4>([&](auto GG) {
+        constexpr int g = decltype(GG)::value, u = g >> 1;
+        if constexpr (g < 3) {
+            constexpr int nu = (g + 1) >> 1, nhl = 1 - ((g + 1) & 1);
+            static_for<0, NT>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<(((T0 + t) * 2 + nu) * 2 + nhl) * 1024>(fq[(g + 1) & 1][t], wf); });
+        }
+        static_for<0, NT>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            constexpr int later = (NT - 1 - t) + (g < 3 ? NT : 0);
+            ws_wait2<later>(fq[g & 1][t], xq[u]);
+            ws_mfma<false, (g == 0)>(accF[t], __builtin_bit_cast(f16x8, fq[g & 1][t]), xq[u]);
+            slot(std::integral_constant<int, g * NT + t>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+}
+
 __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgFwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_act0[AG_WS_SLOTS0][AG_WS_SET];    // input sets of RE1 (ring of two blocks)
@@ -1381,58 +1418,27 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     };
 
     if (wave == 0) {
-        // ---------------------------------------------------------------- first layer, RE1 tiles 0-2
+        // ---------------------------------------------------------------- first layer tiles 0-2, RE1 tiles 0-2
 #pragma unroll
         for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + k) * AG_CHUNK_F4, wsc + (size_t)((1 + k) - 1) * 128, lane);
         __syncthreads();
-        f32x16 accF[5], accP[3];
+        f32x16 accF[3], accP[3];
         zero(accF); zero(accP);
         const unsigned wf = lds_addr_of(s_wf) + lane * 16;
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i0 = r - AG_WS_LAG_F, i1 = r - AG_WS_LAG_1;
             lds_u8 *outF = img(0, i0), *outPp = img(1, i1 - 1);
-            // first layer of block i0: 5 out-tiles x 2 k16-steps x (lo, hi), A fragments from LDS (five independent chains; two products:
-            // the inputs carry their own residuals in spare K slots);  shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores in 20 slots)
-            {
-                const unsigned lin = lds_addr_of(&s_in0[slot_of(i0)][lane * 16]);
-                bf16x8 xq[2], fq[2][5];
-                lds_read16<0>(xq[0], lin);
-                lds_read16<1024>(xq[1], lin);
-                static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + 0) * 2 + 1) * 1024>(fq[0][t], wf); });
-                static_for<0, 4>([&](auto GG) {
-                    constexpr int g = decltype(GG)::value, u = g >> 1;          // groups: (u0, lo) (u0, hi) (u1, lo) (u1, hi)
-                    if constexpr (g < 3) {
-                        constexpr int nu = (g + 1) >> 1, nhl = 1 - ((g + 1) & 1);
-                        static_for<0, 5>([&](auto T) { constexpr int t = decltype(T)::value; lds_read16<((t * 2 + nu) * 2 + nhl) * 1024>(fq[(g + 1) & 1][t], wf); });
-                    }
-                    static_for<0, 5>([&](auto T) {
-                        constexpr int t = decltype(T)::value;
-                        constexpr int later = (4 - t) + (g < 3 ? 5 : 0);
-                        ws_wait2<later>(fq[g & 1][t], xq[u]);
-                        ws_mfma<false, (g == 0)>(accF[t], __builtin_bit_cast(f16x8, fq[g & 1][t]), xq[u]);
-                        constexpr int m = g * 5 + t;                           // 0..19
-                        if constexpr (m < 4) {                                 // two micro-chores in the first four slots
-                            ws_act_micro<0, 2 * m>(accP[0], Ep, outPp, h);
-                            ws_act_micro<0, 2 * m + 1>(accP[0], Ep, outPp, h);
-                        } else {
-                            constexpr int c = m + 4;                           // 8..23
-                            ws_act_micro<c / 8, c % 8>(accP[c / 8], Ep, outPp, h);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                });
-            }
+            // first layer of block i0, tiles 0-2 (12 MFMAs);  shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores, in pairs)
+            ws_first_layer<0, 3>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, [&](auto MM) {
+                constexpr int m = decltype(MM)::value;                     // 0..11
+                ws_act_micro<(2 * m) / 8, (2 * m) % 8>(accP[(2 * m) / 8], Ep, outPp, h);
+                ws_act_micro<(2 * m + 1) / 8, (2 * m + 1) % 8>(accP[(2 * m + 1) / 8], Ep, outPp, h);
+            });
             const unsigned la = lds_addr3(img(0, i1));
-            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, G, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish the first layer (40 micro-chores in 30 slots)
+            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, G, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish first-layer tiles 0-2 (24 micro-chores in 30 slots)
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 10) {
-                    ws_act_micro<(2 * p) / 8, (2 * p) % 8>(accF[(2 * p) / 8], Ep, outF, h);
-                    ws_act_micro<(2 * p + 1) / 8, (2 * p + 1) % 8>(accF[(2 * p + 1) / 8], Ep, outF, h);
-                } else {
-                    constexpr int c = p + 10;                           // 20..39
-                    ws_act_micro<c / 8, c % 8>(accF[c / 8], Ep, outF, h);
-                }
+                if constexpr (p < 24) ws_act_micro<p / 8, p % 8>(accF[p / 8], Ep, outF, h);
             });
             ws_round_barrier();
         }
@@ -1544,23 +1550,30 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         }
         if (Q.nonfinite && a.status) atomicOr(a.status, 1);
     } else {
-        // ---------------------------------------------------------------- We tiles 1-4
+        // ---------------------------------------------------------------- first layer tiles 3-4, We tiles 1-4
 #pragma unroll
         for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(11 + 1 + k) * AG_CHUNK_F4, wsc + (size_t)((11 + 1 + k) - 1) * 128, lane);
         ws_load_unit<false>(W[3], ws + (size_t)(11 + 4) * AG_CHUNK_F4, wsc + (size_t)((11 + 4) - 1) * 128, lane);
         __syncthreads();
-        f32x16 accP[2], accQ[2];
-        zero(accP); zero(accQ);
+        f32x16 accF[2], accP[2], accQ[2];
+        zero(accF); zero(accP); zero(accQ);
         WsQ16 Q{0u, AG_Q16_EB_MIN, 0.0f, {0u, 0u, 0u, 0u}, 0u};
+        const unsigned wf = lds_addr_of(s_wf) + lane * 16;
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            const int i3 = r - AG_WS_LAG_3;
-            const unsigned la3 = lds_addr3(img(2, i3));
+            const int i0 = r - AG_WS_LAG_F, i3 = r - AG_WS_LAG_3;
+            lds_u8 *outF = img(0, i0);
             unsigned char *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
-            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: store We tiles 3, 4 of the previous block
+            // first layer of block i0, tiles 3-4 (8 MFMAs);  shadow: store We tiles 3, 4 of the previous block (14 chores, in pairs)
+            ws_first_layer<3, 2>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, [&](auto MM) {
+                constexpr int m = decltype(MM)::value;                     // 0..7
+                if constexpr (2 * m < 14) ws_q16_chore<3 + (2 * m) / 7, (2 * m) % 7>(accQ[(2 * m) / 7], Q, rowp, h);
+                if constexpr (2 * m + 1 < 14) ws_q16_chore<3 + (2 * m + 1) / 7, (2 * m + 1) % 7>(accQ[(2 * m + 1) / 7], Q, rowp, h);
+            });
+            const unsigned la3 = lds_addr3(img(2, i3));
+            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: finish first-layer tiles 3, 4 (16 micro-chores)
                 constexpr int p = decltype(PP)::value;
-                if constexpr (p < 7) ws_q16_chore<3, p>(accQ[0], Q, rowp, h);
-                if constexpr (p >= 10 && p < 17) ws_q16_chore<4, p - 10>(accQ[1], Q, rowp, h);
+                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accF[p / 8], Ep, outF, h);
             });
             ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 3, 4;  shadow: store We tiles 1, 2
                 constexpr int p = decltype(PP)::value;

@@ -60,10 +60,13 @@ FLOP_PER_EDGE = 2 * (17 * 150 + 3 * 150 * 150)   # F_min edge work: encoder 17->
 PRECISIONS = {"f32": 0, "bf16x3": 1, "fast": 2}
 DTYPE = {"f32": "f32 (exact fp32 MFMA)",
          "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
-         "fast": "node stacks: f32 operands split hi+lo bf16, 3 bf16 MFMAs per product; edge stack: f16 activations x split-f16 (hi+lo) "
-                 "weights, 2 f16 MFMAs per product; f32 accumulate; per-edge table stored f16"}
-EDGE_PRODUCTS = {"f32": 1, "bf16x3": 3, "fast": 2}     # MFMAs issued per fp32 product in the edge stack
-DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16x2+bf16x3"}
+         "fast": "node stacks: f32 operands split hi+lo bf16, 3 bf16 MFMAs per product; edge stack: f16(W) x f16(x) on the f16 MFMA + "
+                 "[e4m3(W_lo) | e4m3(W_hi)] x [e5m2(x) | e5m2(x - f16(x))] on the block-scaled fp8 MFMA (W and x to ~2^-15); f32 accumulate; "
+                 "per-edge table 16-bit block-scaled fixed point (q16)"}
+# fp16-MFMA-times issued per fp32 product in the edge stack: split-bf16 3; "fast": ten f16 MFMAs + five scaled fp8 MFMAs (K = 64, 1.25 f16-MFMA-times
+# each under the power limit, tools/ubench/mx_mfma.hip) per 160 x 32 out-tile = 16.25 / 10
+EDGE_PRODUCTS = {"f32": 1, "bf16x3": 3, "fast": 1.625}
+DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16+fp8corr+bf16x3"}
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -216,14 +219,26 @@ class Engine:
         for _ in range(warmup):
             out = one_pass()
         self.sync()
+        # the model's sticky numeric status (ag_model_status) is read-and-cleared by every dynamics() call: OR what those reads see, so the
+        # line says whether ANY timed pass left the arithmetic's range (the final read below covers the last pass)
+        status, take = [int(self.model.take_status())], self.model.take_status
+
+        def recording_take(device=None):
+            v = take(device)
+            status[0] |= int(v)
+            return v
+
+        self.model.take_status = recording_take
         t0 = time.perf_counter()
         for _ in range(steps):
             out = one_pass(timing)
         self.sync()
         dt = time.perf_counter() - t0
+        self.model.take_status = take
+        status[0] |= int(self.model.take_status())
         assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and bool(torch.isfinite(out["state_seqs"]).all())
         res = {"B_global": B_global, "dt": dt, "ms_per_step": dt / steps * 1e3, "value": B_global * T * steps / dt,
-               "roofline": None, "roofline_hbm": None, "kernels": None}
+               "roofline": None, "roofline_hbm": None, "kernels": None, "model_status": status[0]}
         if timing:
             res["rank_ms"] = (agdist.elapsed_ms(timing["rollout"]) / steps, agdist.elapsed_ms(timing["gather"]) / steps)
         if profile:
@@ -267,7 +282,7 @@ class Engine:
                     "algorithmic_bytes": e_per * ((320 if precision == "fast" else 640) + 68),
                     "avg_launch_ms": ms[k] / cnt[k], "edges_per_launch": e_per, "flop_per_edge": FLOP_PER_EDGE,
                     "mfma": {"f32": "v_mfma_f32_32x32x2_f32", "bf16x3": "v_mfma_f32_32x32x16_bf16, 3 per fp32 product (hi*hi + hi*lo + lo*hi)",
-                             "fast": "v_mfma_f32_32x32x16_f16, 2 per fp32 product (w_lo*x + w_hi*x, x rounded to f16)"}[precision],
+                             "fast": "10 x v_mfma_f32_32x32x16_f16 (f16(W).f16(x)) + 5 x v_mfma_scale_f32_32x32x64_f8f6f4 (corrections) per out-tile"}[precision],
                     "measured": f"HIP events on the launch stream, {n_prof} single-stream passes after the timed region"}
             ka = _lib.KERNEL_CLASSES.index("aggregate")
             if cnt[ka] > 0 and ms[ka] > 0:
@@ -305,7 +320,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event roofline pass")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (f32 mode, granular-2k, cloth-4k)")
     ap.add_argument("--precision", default="fast", choices=sorted(PRECISIONS),
-                    help="engine arithmetic mode; all three pass the 1e-4 parity gate (tests/test_gpu_parity.py)")
+                    help="engine arithmetic mode: f32 = exact fp32 MFMA, bf16x3 = split-bf16, fast (default) = bf16x3 node stacks + fp16 edge stack "
+                         "with fp8 corrections + q16 table; all three hold the 1e-4 gate at any motion size with model_status 0 "
+                         "(tests/test_gpu_parity.py, tools/fuzz_parity.py)")
     ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
     args = ap.parse_args()
 
@@ -351,26 +368,27 @@ def main():
         extra = {}
         if args.precision != "f32":
             e = eng.run(args.batch, T, "f32", args.streams, max(2, args.steps // 2), 1, profile=not args.no_profile)
-            extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"],
+            extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "model_status": e["model_status"],
                                  "arithmetic": DTYPE["f32"], "roofline": e["roofline"],
                                  "note": "same workload, ag_set_option(precision, 0): the mode that matches every reference rollout golden"}
-        if args.precision == "fast":      # the middle mode: fp32-class operands everywhere (measured <= 1.2e-6 on the trained goldens, fast: <= 4.7e-5)
+        if args.precision == "fast":      # the middle mode: split-bf16 everywhere, fp32 per-edge table
             e = eng.run(args.batch, T, "bf16x3", args.streams, max(2, args.steps // 2), 1, profile=False)
             extra["bf16x3_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "arithmetic": DTYPE["bf16x3"],
+                                    "model_status": e["model_status"],
                                     "note": "same workload, ag_set_option(precision, 1)"}
         if args.weights == "seed0":       # throughput does not depend on the weights; the numeric status must stay clean on trained ones too
             et = Engine(args.material, dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained_rope.npz"))), dev, world)
             x = et.run(args.batch, T, args.precision, args.streams, max(2, args.steps // 2), 1, profile=False)
             extra["trained_weights"] = {"value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"], "precision": args.precision,
                                         "weights": "trained_rope (the reference's train() on a toy dataset, tools/gen_trained.py)",
-                                        "model_status": int(et.model.take_status())}
+                                        "model_status": x["model_status"]}
             del et
         extra["workloads"] = {}
         for mat, b, t, tag in (("granular", 128, 10, "BASELINE configs[2]"), ("cloth", 64, 20, "BASELINE configs[3], per-GPU share of batch 512 on 8 GPUs")):
             e2 = Engine(mat, weights, dev, world)
             x = e2.run(b, t, args.precision, args.streams, 3, 1, profile=not args.no_profile)
             extra["workloads"][mat] = {"workload": f"{mat} {WORKLOADS[mat]['n_obj']} particles, batch {b}, {t}-step rollout ({tag})",
-                                       "value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"],
+                                       "value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"], "model_status": x["model_status"],
                                        "precision": args.precision, "kernels": x["kernels"], "roofline": x["roofline"],
                                        "roofline_hbm": x["roofline_hbm"]}
             del e2
@@ -399,9 +417,20 @@ def main():
                        "global_batch": r["B_global"], "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather",
                        "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)" if args.weights == "seed0" else
                                   f"{args.weights} (the reference's train() on a toy dataset, tools/gen_trained.py)",
-                       "precision": args.precision, "arithmetic": DTYPE[args.precision]},
+                       "precision": args.precision, "arithmetic": DTYPE[args.precision],
+                       # 0 = no timed pass left the arithmetic's range (include/adaptigraph_hip.h: ag_model_status)
+                       "model_status": r["model_status"]},
             "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }
+        if extra:       # the driver's record keeps `config`, not `extra`: the per-mode throughputs and statuses of the same workload go here too
+            modes = {args.precision: {"value": line["value"], "model_status": r["model_status"]}}
+            for key, name in (("f32_mode", "f32"), ("bf16x3_mode", "bf16x3")):
+                if key in extra:
+                    modes[name] = {"value": extra[key]["value"], "model_status": extra[key]["model_status"]}
+            line["config"]["modes"] = modes
+            if "trained_weights" in extra:
+                line["config"]["trained_weights"] = {"value": extra["trained_weights"]["value"], "model_status": extra["trained_weights"]["model_status"]}
+            line["config"]["other_workloads"] = {k: {"value": v["value"], "model_status": v["model_status"]} for k, v in extra.get("workloads", {}).items()}
         if ranks:
             line["ranks"] = ranks
         if extra:

@@ -555,9 +555,11 @@ def test_rollout_at_the_benchmarked_config_vs_oracle(material, n_obj, batch, ste
     ref, _ = ago.dynamics(weights, configs.task_config(material), state, act[pick])
     err = np.abs(sub.cpu().numpy() - ref).reshape(len(pick), -1).max(1)
     assert float(np.abs(ref[0, 0] - state).max()) > 1e-3, "the pushed cloud must actually move"
-    assert prec != "f32" or (err <= TOL_FWD).all(), err
+    # exact-fp32 mode: inside the gate after all steps, or — granular-2k saturates its top-20 with candidates a few 1e-7 apart — a PROVEN
+    # top-k near-tie (explain_divergence raises unless the first differing edge list differs only by such candidates); no drift allowance
+    assert prec != "f32" or material == "granular" or (err <= TOL_FWD).all(), err
     for b in np.nonzero(err > TOL_FWD)[0]:      # 10-20 steps: per-step parity on identical graphs is the gate, the accumulated drift is reported
-        step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=True)
+        step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=(prec != "f32"))
         print(f"{material} {prec} sample {pick[b]}: rollout drift {err[b]:.2e} after {steps} steps; max one-step deviation on identical graphs {dev:.2e}"
               + (f"; top-k near-tie at step {step} (candidates {gap:.2e} apart)" if step else "; edge lists equal the reference's at every step"))
 
