@@ -27,6 +27,7 @@ __device__ __forceinline__ void filler2(float &d, float &e)      // two independ
 // 6: f16 MFMAs of both accumulators first (f1a f1b f2a f2b), then each scaled MFMA followed by two interleaved 9-instruction chains
 // 7: triple by triple, back to back, each triple followed by two interleaved 9-instruction chains
 // 8: as 7 with ONE 18-instruction chain                9: as 7 with the chains split: one after the second f16 MFMA, one after the scaled one
+// 10: the fp16 part as FOUR v_mfma_f32_32x32x8_f16 (same work, twice the instructions), scaled MFMA, then [9|9]      11: 32x32x8 f16 alone (4 chains)
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k(const v8i *g, float *out, unsigned long long *cyc, int iters)
 {
@@ -57,6 +58,29 @@ __global__ __launch_bounds__(256, 1) void k(const v8i *g, float *out, unsigned l
             } else if constexpr (MODE == 3) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(u + c) % 4], b[u % 4], acc[c], 4, 4, 0, sc, 0, sc);
+            } else if constexpr (MODE == 11) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    const f16x8 x = __builtin_bit_cast(f16x8, __builtin_shufflevector(a[(u + c) % 4], a[(u + c) % 4], 0, 1, 2, 3));
+                    const f16x8 y = __builtin_bit_cast(f16x8, __builtin_shufflevector(b[u % 4], b[u % 4], 0, 1, 2, 3));
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(x, x, 0, 1, 2, 3), __builtin_shufflevector(y, y, 0, 1, 2, 3), acc[c], 0, 0, 0);
+                }
+            } else if constexpr (MODE == 10) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f16x8 x = __builtin_bit_cast(f16x8, __builtin_shufflevector(a[(u + c) % 4], a[(u + c) % 4], 0, 1, 2, 3));
+                    const f16x8 y = __builtin_bit_cast(f16x8, __builtin_shufflevector(b[u % 4], b[u % 4], 0, 1, 2, 3));
+                    const f16x8 x2 = __builtin_bit_cast(f16x8, __builtin_shufflevector(a[(u + c) % 4], a[(u + c) % 4], 4, 5, 6, 7));
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(x, x, 0, 1, 2, 3), __builtin_shufflevector(y, y, 0, 1, 2, 3), acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(x, x, 4, 5, 6, 7), __builtin_shufflevector(y, y, 4, 5, 6, 7), acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(x2, x2, 0, 1, 2, 3), __builtin_shufflevector(y, y, 0, 1, 2, 3), acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_shufflevector(x2, x2, 4, 5, 6, 7), __builtin_shufflevector(y, y, 4, 5, 6, 7), acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(u + c + 1) % 4], b[u % 4], acc[c], 0, 1, 0, sc, 0, sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    filler2<9>(f0, f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else if constexpr (MODE == 6) {
                 const f16x8 y = __builtin_bit_cast(f16x8, __builtin_shufflevector(b[u % 4], b[u % 4], 0, 1, 2, 3));
 #pragma unroll
@@ -121,16 +145,17 @@ int main()
     hipMalloc(&g, h.size() * 4); hipMemcpy(g, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&o, 512 * 256 * 4); hipMalloc(&c, 512 * 8);
     const int iters = 400;
-    const char *names[10] = {"f16 32x32x16 (4 chains)", "scaled fp8 x bf8 32x32x64 (4 chains)", "scaled fp6 32x32x64 (4 chains)", "scaled fp4 32x32x64 (4 chains)",
+    const char *names[12] = {"f16 32x32x16 (4 chains)", "scaled fp8 x bf8 32x32x64 (4 chains)", "scaled fp6 32x32x64 (4 chains)", "scaled fp4 32x32x64 (4 chains)",
                              "triple f16, f16, scaled fp8 (2 chains)", "triple: f16 [9] f16 MX [9]", "f1a f1b f2a f2b, MX [9|9] x2", "triple back to back, then [9|9]",
-                             "triple back to back, then [18]", "triple: f16 f16 [9] MX [9]"};
+                             "triple back to back, then [18]", "triple: f16 f16 [9] MX [9]",
+                             "4 x 32x32x8 f16 + MX, then [9|9]", "f16 32x32x8 (4 chains)"};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     // short launches (0.2 ms: the power controller has not reacted) and long ones (tens of ms on every CU: the sustained, power-limited state);
     // wall time per instruction next to the s_memtime ticks tells whether the counter follows the throttled clock
     for (int grid : {1, 256})
         for (int iters : {400, 40000}) {
             if (grid == 1 && iters > 400) continue;
-            for (int mode = 0; mode < 10; ++mode) {
+            for (int mode = 0; mode < 12; ++mode) {
                 float ms = 0;
                 for (int rep = 0; rep < 3; ++rep) {
                     hipEventRecord(e0);
@@ -144,16 +169,18 @@ int main()
                     case 6: hipLaunchKernelGGL(k<6>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
                     case 7: hipLaunchKernelGGL(k<7>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
                     case 8: hipLaunchKernelGGL(k<8>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
-                    default: hipLaunchKernelGGL(k<9>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
+                    case 9: hipLaunchKernelGGL(k<9>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
+                    case 10: hipLaunchKernelGGL(k<10>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
+                    default: hipLaunchKernelGGL(k<11>, dim3(grid), dim3(256), 0, 0, g, o, c, iters); break;
                     }
                     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
                 }
                 std::vector<unsigned long long> hc(grid);
                 hipMemcpy(hc.data(), c, grid * 8, hipMemcpyDeviceToHost);
                 double avg = 0; for (auto v : hc) avg += v; avg /= grid;
-                const double n = mode < 4 ? iters * 8.0 * 4 : iters * 8.0 * 2;      // instructions (or triples) per wave
+                const double n = (mode < 4 || mode == 11) ? iters * 8.0 * 4 : iters * 8.0 * 2;      // instructions (or triples) per wave
                 printf("grid %3d iters %5d  %-42s %7.1f ticks, %7.2f ns per %s  (launch %.2f ms, %.2f ticks/ns)\n", grid, iters, names[mode], avg / n, ms * 1e6 / n,
-                       mode < 4 ? "instruction" : "triple", ms, avg / (ms * 1e6));
+                       (mode < 4 || mode == 11) ? "instruction" : "triple", ms, avg / (ms * 1e6));
             }
         }
     return 0;
