@@ -189,13 +189,14 @@ __device__ __forceinline__ int q16_tile_exp(unsigned m, bool &nonfinite)
     const int eb = (int)(m >> 23);
     return eb < AG_Q16_EB_MIN ? AG_Q16_EB_MIN : (eb > AG_Q16_EB_MAX ? AG_Q16_EB_MAX : eb);
 }
-__device__ __forceinline__ float q16_inv_scale(int eb) { return __uint_as_float((unsigned)(253 - eb) << 23); }      // 2^(126 - eb)
-__device__ __forceinline__ unsigned q16_pack(float a, float b, float inv)          // two values -> packed snorm16 (round to nearest)
+__device__ __forceinline__ int q16_inv_scale(int eb) { return 126 - eb; }          // the tile's values are scaled by 2^(126 - eb)
+// two values -> packed snorm16 (round to nearest).  The scaling is v_ldexp_f32, one per value, NOT one v_pk_mul_f32 per pair: the packed fp32
+// instructions take ~39 cycles beside a busy matrix pipe against ~10 for an ordinary VALU instruction (tools/ubench/valu_beside_mfma.hip), and
+// this runs in the shadow of MFMAs in every edge kernel.  (ldexp by 2^k and the multiplication by 2^k round identically: same bits.)
+__device__ __forceinline__ unsigned q16_pack(float a, float b, int inv)
 {
     typedef short s16x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 v = f32x2{a, b} * f32x2{inv, inv};                                 // v_pk_mul_f32
-    return __builtin_bit_cast(unsigned, (s16x2)__builtin_amdgcn_cvt_pknorm_i16(v[0], v[1]));
+    return __builtin_bit_cast(unsigned, (s16x2)__builtin_amdgcn_cvt_pknorm_i16(__builtin_ldexpf(a, inv), __builtin_ldexpf(b, inv)));
 }
 // stores of one out-tile of lane (j, h): `row` = table + e * 320 bytes; the lane's 32 bytes start at 64 ti + 32 h.  In tile 4 the last eight
 // bytes of the lane's chunk are padding that holds exponent bytes written by OTHER lanes / waves: they are not touched.
@@ -223,7 +224,7 @@ struct RowStoreQ16Epi {     // Eterm as q16 (precision mode 2).  The maximum run
         for (int r = 0; r < 16; r += 2) m = q16_max2<true>(m, v[r], v[r + 1]);
         bool bad;
         const int eb = q16_tile_exp(m, bad);
-        const float inv = q16_inv_scale(eb);
+        const int inv = q16_inv_scale(eb);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             unsigned w[4];
@@ -1115,7 +1116,7 @@ typedef h3_u32x4 ws_u32x4;
 typedef int ws_i32x2 __attribute__((ext_vector_type(2)));
 
 // ACC: keep the unit in the accumulation-register half of the file; a wave holds three units (240 registers) there.
-template <bool ACC>
+template <bool ACC, bool ACC_MX = ACC>
 __device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, const uint32_t *scales, int lane)
 {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void ws_load_unit(WsUnit &W, const float4 *chunk, con
 #pragma unroll
     for (int u = 0; u < 10; ++u) { if (ACC) asm volatile("" : "+a"(W.hi[u])); else asm volatile("" : "+v"(W.hi[u])); }
 #pragma unroll
-    for (int t = 0; t < AG_NT; ++t) { if (ACC) asm volatile("" : "+a"(W.mx[t])); else asm volatile("" : "+v"(W.mx[t])); }
+    for (int t = 0; t < AG_NT; ++t) { if (ACC_MX) asm volatile("" : "+a"(W.mx[t])); else asm volatile("" : "+v"(W.mx[t])); }
     asm volatile("" : "+v"(W.sc0), "+v"(W.sc1));
 }
 __device__ __forceinline__ unsigned lds_addr3(const __attribute__((address_space(3))) void *p) { return (unsigned)(uintptr_t)p; }
@@ -1187,12 +1188,11 @@ struct WsRing {
 // >= 3 MFMAs later.  slot(IC<2p>), slot(IC<2p + 1>) run after triple p = t * NA + k (slot numbers 0 .. 10 NA - 1, in order).
 // With NEXT_NIN > 0 the phase also issues the reads of tile 0 of the NEXT phase (NEXT_NIN input sets at na0 / na1) during its own tile 4,
 // and that phase is instantiated with PRE = true and the ring offset RO = 1 (its tile t sits in ring slot (t + RO) % 2).
-template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, class Slot>
-__device__ __forceinline__ void ws_phase(const WsUnit (&W)[4], f32x16 (&acc)[NA0 + NA1], WsRing &G, unsigned la0, unsigned la1,
+template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, int NW, class Slot>
+__device__ __forceinline__ void ws_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NA0 + NA1], WsRing &G, unsigned la0, unsigned la1,
                                          unsigned na0, unsigned na1, Slot &&slot)
 {
     constexpr int NIN = NA1 ? 2 : 1, NA = NA0 + NA1;
-    static_assert(NA >= 2, "a lone accumulator chain would have every chore between its dependent MFMAs");
     auto issue = [&](auto TT) {
         constexpr int t = decltype(TT)::value, ri = (t + RO) % 2;
         if constexpr (t < AG_NT) {
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, lds_u8
 // 2 the tile exponent (partner half by v_permlane32_swap) and its byte, 3..6 two packed converts each, 4 and 6 store 16 (8) bytes.
 // Branch-free on purpose: a store under `if (block is valid)` made the compiler sink the whole tile's converts into the conditional block.
 // Rows of blocks outside the launch go to 32 dump rows behind the table (the 16-bit table uses half of its fp32-sized allocation).
-struct WsQ16 { unsigned m; int eb; float inv; unsigned w[4]; unsigned nonfinite; };
+struct WsQ16 { unsigned m; int eb; int inv; unsigned w[4]; unsigned nonfinite; };
 template <int T, int C>
 __device__ __forceinline__ void ws_q16_chore(const f32x16 &acc, WsQ16 &Q, unsigned char *row, int h)
 {
@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         __syncthreads();
         f32x16 accP[2], accQ[2];
         zero(accP); zero(accQ);
-        WsQ16 Q{0u, AG_Q16_EB_MIN, 0.0f, {0u, 0u, 0u, 0u}, 0u};
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
             const int i2 = r - AG_WS_LAG_2, i3 = r - AG_WS_LAG_3;
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         __syncthreads();
         f32x16 accF[2], accP[2], accQ[2];
         zero(accF); zero(accP); zero(accQ);
-        WsQ16 Q{0u, AG_Q16_EB_MIN, 0.0f, {0u, 0u, 0u, 0u}, 0u};
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
         const unsigned wf = lds_addr_of(s_wf) + lane * 16;
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
@@ -1586,6 +1586,324 @@ __global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     }
     h3_report(Ep.bad, a.status);
 }
+
+// =====================================================================================================================
+// The same dataflow on EIGHT waves (two per SIMD, 256 registers each): edge_encode_ws8_kernel.
+//
+// tools/ubench/mx_lone.hip: a lone wave does not overlap its own VALU work with its own matrix instructions (a triple of 128 pipe cycles
+// followed by 18 VALU instructions takes 183), but a SECOND wave on the SIMD hides them completely (257 cycles for both waves' triple + 18
+// VALU: the pipe never idles).  With four waves of 512 registers every epilogue instruction of edge_encode_ws_kernel is paid in matrix-pipe idle
+// time (round 5 600 cycles for 2 560 of pipe work); here a wave keeps TWO units (160 accumulation registers), runs their 30 matrix instructions,
+// then their epilogues as plain code — no micro-chores, no deferred epilogues — while its SIMD partner is in the other half of its round:
+//     wave 0, 1: RE1 tiles {0,1}, {2,3}      wave 2, 3: RE2 tiles {0,1}, {2,3}      wave 4, 5: first-layer tile 0 / 1 + We tiles {0,1}, {2,3}
+//     wave 6: RE1 tile 4, RE2 tile 4         wave 7: input gather, first-layer tiles 2-4, We tile 4
+// (waves w and w + 4 share a SIMD: 2 560-2 820 pipe cycles per SIMD and round).  Block i: gathered in rounds i .. i + 2, first layer in round
+// i + 3, RE1 i + 4, RE2 i + 5, We i + 6; every set ring is two blocks deep, one barrier per round; LDS 116 KB.
+// Every accumulator sees the same products in the same order as in the other two edge kernels: same bits.
+// =====================================================================================================================
+#define AG_WS8_LAG_F 3
+#define AG_WS8_LAG_1 4
+#define AG_WS8_LAG_2 5
+#define AG_WS8_LAG_3 6
+// An asm MFMA's result is not interlocked against the VALU instructions the compiler places after it: 16 passes + 4 states for the scaled one
+__device__ __forceinline__ void ws8_settle(f32x16 &a) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a)); }
+__device__ __forceinline__ void ws8_settle(f32x16 &a, f32x16 &b) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void ws8_settle(f32x16 &a, f32x16 &b, f32x16 &c) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c)); }
+// One MFMA phase of the eight-wave kernel: accumulators 0 .. NA-1 run units W[0 .. NA-1] on ONE input set (la: this lane's 16 bytes of k16-step 0).
+// The compiler splits a 256-register wave into 128 + 128: a wave's first unit and the fp16 half of its second live in accumulation registers
+// (NACC2 half-units: fp16 fragments of unit k = half-unit 2k, its scaled-MFMA operands = half-unit 2k + 1), the rest in architectural ones.
+// No operand ring: the partner wave's matrix work covers the LDS latency.  The next tile's reads are issued after the fp16 MFMAs that read the
+// current fragments and land during the scaled MFMAs; the scaled MFMA's B operand (read over several passes after issue) alternates between two
+// register sets by tile parity.
+#ifdef AG_WS_TRACE
+__device__ unsigned long long g_ws8_tiles[8 * 16 * 8];
+#define WS8_TILE(k) do { if (tr >= 0 && lane_ == 0) g_ws8_tiles[tr * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS8_TILE(k)
+#endif
+template <int NA, int NACC2, int U0 = 0, int NW, int NACCS>
+__device__ __forceinline__ void ws8_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NACCS], unsigned la, int tr = -1)
+{
+    const int lane_ = threadIdx.x & 63; (void)lane_;
+    WS8_TILE(0);
+    bf16x8 xa, xb, r;
+    lds_read16<0>(xa, la);
+    lds_read16<1024>(xb, la);
+    lds_read16<AG_WS_IMG>(r, la);
+    const unsigned one = 0x7f7f7f7fu;      // E8M0 127 = 2^0: the activations' bytes are plain e5m2 numbers
+    h3_i32x8 Bq[2];
+    static_for<0, AG_NT>([&](auto TT) {
+        constexpr int t = decltype(TT)::value;
+        ws_wait3<0>(xa, xb, r);
+        h3_i32x8 &B = Bq[t & 1];
+        B = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa), __builtin_bit_cast(h3_u32x4, xb)), __builtin_bit_cast(h3_u32x4, r));
+        asm volatile("s_nop 1" : "+v"(B));      // VALU write -> asm MFMA read: two wait states
+        // A dependent MFMA issued straight after its predecessor uses the pipe's accumulate path; with ONE other MFMA between them it waits for the
+        // predecessor's write-back (traced: 480 cycles per tile of two accumulators in the order a b a b a b, pipe time 256)
+        static_for<0, NA>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            ws_mfma<(2 * (U0 + k) < NACC2), (t == 0)>(acc[U0 + k], W[U0 + k].hi[2 * t], xa);
+            ws_mfma<(2 * (U0 + k) < NACC2), false>(acc[U0 + k], W[U0 + k].hi[2 * t + 1], xb);
+        });
+        if constexpr (t + 1 < AG_NT) {
+            lds_read16<(2 * t + 2) * 1024>(xa, la);
+            lds_read16<(2 * t + 3) * 1024>(xb, la);
+            lds_read16<AG_WS_IMG + (t + 1) * 1024>(r, la);
+        }
+        static_for<0, NA>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            ws_mfma_mx<(2 * (U0 + k) + 1 < NACC2), (t & 3)>(acc[U0 + k], W[U0 + k].mx[t], B, t < 4 ? W[U0 + k].sc0 : W[U0 + k].sc1, one);
+        });
+        if constexpr (t > 0) asm volatile("" :: "v"(Bq[(t - 1) & 1]));      // the previous tile's operand is released only now
+        WS8_TILE(t + 1);
+    });
+    asm volatile("" :: "v"(Bq[(AG_NT - 1) & 1]));
+}
+template <int T>
+__device__ __forceinline__ void ws8_hidden_tile(const f32x16 &acc, WsEpi &E, lds_u8 *set_lane, int h)
+{
+    static_for<0, 8>([&](auto MM) { ws_act_micro<T, decltype(MM)::value>(acc, E, set_lane, h); });
+}
+template <int T>
+__device__ __forceinline__ void ws8_table_tile(const f32x16 &acc, WsQ16 &Q, unsigned char *row, int h)
+{
+    static_for<0, 7>([&](auto CC) { ws_q16_chore<T, decltype(CC)::value>(acc, Q, row, h); });
+}
+
+#ifdef AG_WS_TRACE      // TEMPORARY: s_memtime stamps of workgroup 3, rounds 100..115 (tools/trace_ws8.py)
+__device__ unsigned long long g_ws8_trace[8 * 16 * 8 + 8];
+#define WS8_T(k) do { if (blockIdx.x == 3 && r >= 100 && r < 116 && lane == 0) g_ws8_trace[(wave * 16 + (r - 100)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS8_T(k)
+#endif
+__global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, AgFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_act[3][2][AG_WS_SET];             // input sets of RE1, RE2, We: rings of two blocks
+    __shared__ __attribute__((aligned(16))) unsigned char s_in0[AG_WS_SLOTS][AG_WS_IN0];      // first-layer inputs
+    __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Mn = a.B * a.N;
+    const int E = a.row_ptr[Mn];
+    if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
+    const int nblk = (E + 31) / 32;
+    if ((int)blockIdx.x >= nblk) return;
+    const int n_i = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup: blockIdx + i * gridDim
+    const int rounds = n_i + AG_WS8_LAG_3 + 1;      // + 1: the We pairs store a block's rows at the start of the next round
+    const float4 *ws = w.edge_encode_h2;
+    for (int i = tid; i < AG_CHUNK_F4; i += 512) s_wf[i] = ws[i];
+    for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 512) reinterpret_cast<float4 *>(&s_act[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 512) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
+    auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
+    // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i (i >= -8)
+    auto img = [&](int layer, int i) -> lds_u8 * { return (lds_u8 *)&s_act[layer][(i + 8) & 1][lane * 16]; };
+    auto eterm_row = [&](int i) {
+        const size_t e = ((i >= 0 && i < n_i) ? (size_t)gblock(i) * 32 : e_pad) + j;
+        return reinterpret_cast<unsigned char *>(a.eterm) + e * (2 * AG_FP);
+    };
+    WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
+#ifdef AG_WS_TRACE
+    if (blockIdx.x == 3 && lane == 0) g_ws8_trace[8 * 16 * 8 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+#endif
+    const uint32_t *wsc = w.edge_scale_h3;      // block scales of unit k (stream chunk 1 + k): wsc + 128 k
+    auto load_unit = [&](WsUnit &U, int chunk) { ws_load_unit<true, true>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };
+    auto load_unit2 = [&](WsUnit &U, int chunk) { ws_load_unit<true, false>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };
+    auto noop = [](auto) {};
+    const unsigned wf = lds_addr_of(s_wf) + lane * 16;
+
+    // hidden layer L (1: RE1, 2: RE2), out-tiles T0 and T0 + 1; then first-layer tile TF (-1: none)
+    auto hidden_pair = [&](auto LL, auto TT, auto FF) {
+        constexpr int L = decltype(LL)::value, T0 = decltype(TT)::value, TF = decltype(FF)::value;
+        WsUnit W[2];
+        load_unit(W[0], 1 + 5 * (L - 1) + T0);
+        load_unit2(W[1], 2 + 5 * (L - 1) + T0);
+        __syncthreads();
+        f32x16 acc[2];
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            const int i = r - (AG_WS8_LAG_F + L);
+            const unsigned la = lds_addr3(img(L - 1, i));
+            lds_u8 *out = img(L, i);
+            WS8_T(0);
+            ws8_phase<2, 3>(W, acc, la, (blockIdx.x == 3 && r >= 100 && r < 116) ? wave * 16 + (r - 100) : -1);
+            WS8_T(3);
+            ws8_settle(acc[0], acc[1]);
+            ws8_hidden_tile<T0>(acc[0], Ep, out, h);
+            ws8_hidden_tile<T0 + 1>(acc[1], Ep, out, h);
+            WS8_T(4);
+            if constexpr (TF >= 0) {
+                const int i0 = r - AG_WS8_LAG_F;
+                f32x16 accF[1];
+                ws_first_layer<TF, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
+                WS8_T(5);
+                ws8_settle(accF[0]);
+                ws8_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
+                WS8_T(6);
+            }
+#ifdef AG_WS_SLEEP
+            __builtin_amdgcn_s_sleep(AG_WS_SLEEP);
+#endif
+            ws_round_barrier();
+            WS8_T(7);
+        }
+    };
+    // We tiles T0 and T0 + 1 and first-layer tile TF.  The round STARTS with the previous round's table epilogue (the SIMD partner starts with its
+    // MFMAs: the two waves stay in opposite halves of their rounds), then the first-layer tile, then this round's MFMAs.
+    auto table_pair = [&](auto FF, auto TT) {
+        constexpr int TF = decltype(FF)::value, T0 = decltype(TT)::value;
+        WsUnit W[2];
+        load_unit(W[0], 11 + T0);
+        load_unit2(W[1], 12 + T0);
+        __syncthreads();
+        f32x16 acc[2], accF[1];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] = acc[1][q] = 0.0f;
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            const int i0 = r - AG_WS8_LAG_F, i3 = r - AG_WS8_LAG_3;
+            WS8_T(0);
+            unsigned char *rowp = eterm_row(i3 - 1);
+            ws8_table_tile<T0>(acc[0], Q, rowp, h);
+            ws8_table_tile<T0 + 1>(acc[1], Q, rowp, h);
+            WS8_T(1);
+            ws_first_layer<TF, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
+            WS8_T(2);
+            ws8_settle(accF[0]);
+            ws8_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
+            WS8_T(3);
+            const unsigned la = lds_addr3(img(2, i3));
+#ifdef AG_WS_SPLIT
+            ws8_phase<1, 3, 0>(W, acc, la);
+            ws8_phase<1, 3, 1>(W, acc, la);
+#else
+            ws8_phase<2, 3>(W, acc, la, (blockIdx.x == 3 && r >= 100 && r < 116) ? wave * 16 + (r - 100) : -1);
+#endif
+            WS8_T(4);
+            ws8_settle(acc[0], acc[1]);
+            ws_round_barrier();
+            WS8_T(7);
+        }
+        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
+    };
+
+    if (wave == 0) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+    else if (wave == 1) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, -1>{});
+    else if (wave == 2) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+    else if (wave == 3) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    else if (wave == 4) table_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    else if (wave == 5) table_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    else if (wave == 6) {
+        // ---------------------------------------------------------------- RE1 tile 4 and RE2 tile 4: two input sets, one after the other
+        WsUnit W[1], W1[1];
+        load_unit(W[0], 1 + 4);
+        load_unit2(W1[0], 6 + 4);
+        __syncthreads();
+        f32x16 accA[1], accB[1];
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            const int i1 = r - AG_WS8_LAG_1, i2 = r - AG_WS8_LAG_2;
+            const unsigned la1 = lds_addr3(img(0, i1)), la2 = lds_addr3(img(1, i2));
+            WS8_T(0);
+            ws8_phase<1, 2>(W, accA, la1);
+            WS8_T(1);
+            ws8_settle(accA[0]);
+            ws8_hidden_tile<4>(accA[0], Ep, img(1, i1), h);
+            WS8_T(2);
+            ws8_phase<1, 1>(W1, accB, la2);
+            WS8_T(3);
+            ws8_settle(accB[0]);
+            ws8_hidden_tile<4>(accB[0], Ep, img(2, i2), h);
+            WS8_T(4);
+            ws_round_barrier();
+            WS8_T(7);
+        }
+    } else {
+        // ---------------------------------------------------------------- per-edge input gather, first-layer tiles 2-4, We tile 4
+        WsUnit W[1];
+        load_unit(W[0], 11 + 4);
+        __syncthreads();
+        f32x16 accF[2], acc[1];
+        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
+        // three blocks in flight: edge indices (this round) -> the two 64-byte node rows (next round) -> features (the round after)
+        int er = 0, es = 0;                // indices of block r (loaded in round r, used in round r + 1)
+        float4 R[4], S[4];                 // receiver / sender rows of block r - 1 (loaded in round r, used in round r + 1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](float x0, float x1) { const f32x2 v = {x0, x1}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); };
+        const float4 *tab = reinterpret_cast<const float4 *>(a.edge_node_tab);
+        static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            const int i0 = r - AG_WS8_LAG_F, i3 = r - AG_WS8_LAG_3;
+            WS8_T(0);
+            {   // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1];
+                // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (slot 16: feature 16, 17: the bias
+                // 1.0, 18..29: the fp16 residuals of features 5..16, f16_residual; the same values in the same slots as edge_encode_kernel<PrecH3>)
+                float feat[24];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
+                feat[0] = R[0].x; feat[1] = R[0].y; feat[2] = S[0].x; feat[3] = S[0].y; feat[4] = fabsf(R[0].z - S[0].z); feat[AG_EDGE_IN] = 1.0f;
+                feat[5] = R[1].x - S[1].x; feat[6] = R[1].y - S[1].y; feat[7] = R[1].z - S[1].z; feat[8] = R[1].w - S[1].w;
+                feat[9] = R[2].x - S[2].x; feat[10] = R[2].y - S[2].y; feat[11] = R[2].z - S[2].z; feat[12] = R[2].w - S[2].w;
+                feat[13] = R[3].x - S[3].x; feat[14] = R[3].y - S[3].y; feat[15] = R[3].z - S[3].z; feat[16] = R[3].w - S[3].w;
+                ws_u32x4 X, X1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+                        X[2 * q + c2] = pk(h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]);
+                // slots 16, 17 | 20, 21 and 18, 19 | 22, 23, then 24, 25 | 28, 29 and 26, 27 | 30, 31   (h = 0 | h = 1; slots 30, 31 stay zero)
+                X1[0] = h ? pk(f16_residual(feat[7]), f16_residual(feat[8])) : pk(feat[16], feat[AG_EDGE_IN]);
+                X1[1] = h ? pk(f16_residual(feat[9]), f16_residual(feat[10])) : pk(f16_residual(feat[5]), f16_residual(feat[6]));
+                X1[2] = h ? pk(f16_residual(feat[15]), f16_residual(feat[16])) : pk(f16_residual(feat[11]), f16_residual(feat[12]));
+                X1[3] = h ? 0u : pk(f16_residual(feat[13]), f16_residual(feat[14]));
+                *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16]) = X;
+                *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024]) = X1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { R[q] = tab[(unsigned)er * 4u + q]; S[q] = tab[(unsigned)es * 4u + q]; }      // node rows of block r - 1
+            {                                                                                                          // edge indices of block r
+                const int e = (r < n_i ? gblock(r) : 0) * 32 + j;
+                const bool valid = r < n_i && e < E;
+                er = valid ? a.edge_recv[e] : 0;
+                es = valid ? a.edge_send[e] : 0;
+            }
+            WS8_T(5);
+            ws_first_layer<2, 2>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
+            WS8_T(1);
+            ws8_settle(accF[0], accF[1]);
+            lds_u8 *outF = img(0, i0);
+            ws8_hidden_tile<2>(accF[0], Ep, outF, h);
+            ws8_hidden_tile<3>(accF[1], Ep, outF, h);
+            WS8_T(2);
+            const unsigned la = lds_addr3(img(2, i3));
+            ws8_phase<1, 2>(W, acc, la);
+            WS8_T(3);
+            ws8_settle(acc[0]);
+            ws8_table_tile<4>(acc[0], Q, eterm_row(i3), h);
+            WS8_T(4);
+            ws_round_barrier();
+            WS8_T(7);
+        }
+        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
+    }
+    h3_report(Ep.bad, a.status);
+}
+#ifdef AG_WS_TRACE
+extern "C" __attribute__((visibility("default"))) int ag_ws_trace_read(unsigned long long *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws8_trace), sizeof(g_ws8_trace));
+}
+extern "C" __attribute__((visibility("default"))) int ag_ws_tiles_read(unsigned long long *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws8_tiles), sizeof(g_ws8_tiles));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // One propagation round at node level: fused segment reduce (aggregate_rows) or a pre-computed `agg` table,
@@ -1935,7 +2253,9 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
             hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(256), 0, s, w, a);   // (always four waves, whatever AG_MLP_THREADS is)
+            const dim3 gws(blocks < slots ? blocks : (slots > 0 ? slots : 1));
+            if (a.edge_ws == 2) hipLaunchKernelGGL(edge_encode_ws8_kernel, gws, dim3(512), 0, s, w, a);     // eight waves, two per SIMD
+            else hipLaunchKernelGGL(edge_encode_ws_kernel, gws, dim3(256), 0, s, w, a);                     // four waves, whatever AG_MLP_THREADS is
             return;
         }
         const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H3_WG_PER_CU));

@@ -28,14 +28,14 @@ __device__ __forceinline__ void filler2(float &d, float &e)      // two independ
 // 7: triple by triple, back to back, each triple followed by two interleaved 9-instruction chains
 // 8: as 7 with ONE 18-instruction chain                9: as 7 with the chains split: one after the second f16 MFMA, one after the scaled one
 // 10: the fp16 part as FOUR v_mfma_f32_32x32x8_f16 (same work, twice the instructions), scaled MFMA, then [9|9]      11: 32x32x8 f16 alone (4 chains)
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void k(const v8i *g, float *out, unsigned long long *cyc, int iters)
+template <int MODE, int THREADS = 256>      // THREADS 512: two waves per SIMD (256 registers each) — does the partner wave's matrix work hide the VALU chains?
+__global__ __launch_bounds__(THREADS, 1) void k(const v8i *g, float *out, unsigned long long *cyc, int iters)
 {
     v16f acc[4];
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     v8i a[4], b[4];
-    for (int u = 0; u < 4; ++u) { a[u] = g[threadIdx.x + 256 * u]; b[u] = g[threadIdx.x + 256 * (4 + u)]; }
+    for (int u = 0; u < 4; ++u) { a[u] = g[(threadIdx.x & 255) + 256 * u]; b[u] = g[(threadIdx.x & 255) + 256 * (4 + u)]; }
     const int sc = 0x7f7f7f7f;
     float f0 = 0.5f, f1 = 0.25f;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void k(const v8i *g, float *out, unsigned l
     float s = f0 + f1;
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 16; ++r) s += acc[c][r];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -181,6 +181,27 @@ int main()
                 const double n = (mode < 4 || mode == 11) ? iters * 8.0 * 4 : iters * 8.0 * 2;      // instructions (or triples) per wave
                 printf("grid %3d iters %5d  %-42s %7.1f ticks, %7.2f ns per %s  (launch %.2f ms, %.2f ticks/ns)\n", grid, iters, names[mode], avg / n, ms * 1e6 / n,
                        (mode < 4 || mode == 11) ? "instruction" : "triple", ms, avg / (ms * 1e6));
+            }
+        }
+    // two waves per SIMD: ticks per triple of ONE wave (the pipe is shared: 256 = fully hidden VALU, 2 x the lone-wave figure = nothing hidden)
+    for (int grid : {1, 256})
+        for (int iters : {400, 40000}) {
+            if (grid == 1 && iters > 400) continue;
+            for (int mode : {4, 7, 8}) {
+                float ms = 0;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0);
+                    if (mode == 4) hipLaunchKernelGGL((k<4, 512>), dim3(grid), dim3(512), 0, 0, g, o, c, iters);
+                    else if (mode == 7) hipLaunchKernelGGL((k<7, 512>), dim3(grid), dim3(512), 0, 0, g, o, c, iters);
+                    else hipLaunchKernelGGL((k<8, 512>), dim3(grid), dim3(512), 0, 0, g, o, c, iters);
+                    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                }
+                std::vector<unsigned long long> hc(grid);
+                hipMemcpy(hc.data(), c, grid * 8, hipMemcpyDeviceToHost);
+                double avg = 0; for (auto v : hc) avg += v; avg /= grid;
+                const double n = iters * 8.0 * 2;
+                printf("2 waves/SIMD grid %3d iters %5d  %-42s %7.1f ticks per triple of one wave, %7.2f ns per triple of the SIMD  (launch %.2f ms, %.2f ticks/ns)\n", grid, iters,
+                       names[mode], avg / n, ms * 1e6 / n / 2, ms, avg / (ms * 1e6));
             }
         }
     return 0;

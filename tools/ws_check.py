@@ -15,9 +15,10 @@ for n, B, seed in ((700, 5, 11), (64, 1, 3), (1000, 64, 5)):
     kw = dict(action=T.t(g["action"]), rope_physics_param=T.t(g["phys"]))
     m.set_option("edge_stationary", 0)
     _, a = m(*args, **kw)
-    m.set_option("edge_stationary", 1)
-    _, b = m(*args, **kw)
-    _, c = m(*args, **kw)
-    torch.cuda.synchronize()
-    print("n", n, "B", B, "E", int(csr.row_ptr[-1].item()), "bitwise equal:", torch.equal(a, b), "repeatable:", torch.equal(b, c),
-          "max diff", (a - b).abs().max().item(), "finite", bool(torch.isfinite(b).all()))
+    for ws in (1, 2):
+        m.set_option("edge_stationary", ws)
+        _, b = m(*args, **kw)
+        _, c = m(*args, **kw)
+        torch.cuda.synchronize()
+        print("n", n, "B", B, "E", int(csr.row_ptr[-1].item()), "kernel", ws, "bitwise equal:", torch.equal(a, b), "repeatable:", torch.equal(b, c),
+              "max diff", (a - b).abs().max().item(), "finite", bool(torch.isfinite(b).all()), "status", m.take_status())
