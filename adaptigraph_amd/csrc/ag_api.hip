@@ -497,7 +497,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
         m->eterm_half = mode == 2;
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
-    if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v);
+    if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
@@ -736,7 +736,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
         if (value != 2 && value != 3) return fail(AG_ERR_ARG, "ag_set_option: edge_products takes 2 (fp16 edge stack, default) or 3 (split-bf16), not %d", value);
         m->edge_products = value;
     }
-    else if (!strcmp(name, "edge_stationary")) m->edge_ws = value;
+    else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;

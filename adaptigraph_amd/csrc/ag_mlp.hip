@@ -161,7 +161,7 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
 };
 
 // ---- q16: the 16-bit per-edge table of precision mode 2 (format: ag_common.h).  The pieces below are shared by the streaming kernels'
-//      epilogue (RowStoreQ16Epi) and the weight-stationary kernel's micro-chores, so both write the same bits. ------------------------------
+//      epilogue (RowStoreQ16Epi) and the weight-stationary kernel's epilogue pieces, so both write the same bits. ------------------------------
 // largest |v| of two values against a running maximum (as a bit pattern; m >= 0).  NANSAFE: compared as unsigned integers — |x| orders
 // like one, and inf / NaN sort above every finite value, so a non-finite accumulator ends up in the block exponent and raises the
 // status bit (the split-bf16 edge stack has no other check).  Otherwise ONE v_max3_f32 with |.| source modifiers: a NaN is dropped, inf
@@ -1067,47 +1067,41 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 }
 
 // =====================================================================================================================
-// Weight-STATIONARY edge encoder (precision mode 2, the three-product arithmetic of PrecH3; the default there, ag_set_option("edge_stationary", 0) selects the streaming kernel).
+// Weight-STATIONARY edge encoder (precision mode 2, arithmetic PrecH3; the default there, ag_set_option("edge_stationary", 0) selects the streaming kernel).
 //
 // The streaming kernels above re-read the whole 320 KB weight image from L2 through LDS for every 128 edges: 2 560 B of
-// L2->LDS traffic and 2 560 B of LDS fragment reads per edge, against 388 B of HBM traffic; in the power-limited regime
-// this kernel runs in that data movement is what is left to save.  Here the dataflow is turned around:
-//  * ONE 256-thread workgroup per CU, one wave per SIMD, 512 registers per lane.  The four layers are cut into 15 "units"
-//    of one 32-feature out-tile (30 MFMAs per 32 edges) plus the narrow first layer (20 MFMAs): every wave owns units worth
-//    110-120 MFMAs per 32-edge block and keeps their A-operand fragments (hi + lo fp16: 80 registers per unit) in REGISTERS for
-//    the whole launch — 300 KB of the CU's 512 KB register file hold the entire edge stack:
-//        wave 0: first-layer tiles 0-2 (fragments in LDS), RE1 tiles 0-2         wave 1: RE1 tiles 3-4, RE2 tiles 0-1, input gather
-//        wave 2: RE2 tiles 2-4, We tile 0                                        wave 3: first-layer tiles 3-4, We tiles 1-4
-//    (the round is set by the wave with the most EPILOGUE work, not by matrix-pipe time — tools/trace_ws.py: with all five first-layer tiles on
-//    one wave that wave needed 5 100 of a 5 900-cycle round while the others waited 650-1 050 cycles at the barrier — so the first layer's
-//    epilogues are split 3 : 2 between the wave with three hidden tiles and the wave with the four cheap table tiles)
-//    Three units of a wave sit in the accumulation half of the register file (the MFMA reads its A operand from there
-//    directly), the fourth and all accumulators in the architectural half (the epilogue's VALU instructions read them directly).
+// L2->LDS traffic and 2 560 B of LDS fragment reads per edge, against 388 B of HBM traffic.  Here the dataflow is turned around:
+//  * ONE 512-thread workgroup per CU, two waves per SIMD, 256 registers per lane.  The four layers are cut into 15 "units" of one
+//    32-feature out-tile (30 matrix instructions per 32 edges) plus the narrow first layer (5 tiles x 4): a wave owns TWO units and keeps
+//    their A operands (fp16 hi fragments + the scaled MFMA's [e4m3 lo | e4m3 hi] operands: 80 registers per unit) in REGISTERS for the
+//    whole launch — the compiler splits a 256-register wave 128 + 128, so a wave's first unit and the fp16 half of its second sit in
+//    accumulation registers (the MFMA reads its A operand from there directly), the rest and all accumulators in architectural ones:
+//        wave 0, 1: RE1 tiles {0,1}, {2,3} + first-layer tile 0 / 1       wave 2, 3: RE2 tiles {0,1}, {2,3} + first-layer tile 2 / 3
+//        wave 4, 5: We tiles {0,1}, {2,3}                                  wave 6: RE1 tile 4, RE2 tile 4
+//        wave 7: We tile 4, per-edge input gather, first-layer tile 4          (waves w and w + 4 share a SIMD)
 //  * 32-edge blocks flow through the waves as a software pipeline; a layer's 160 x 32 activation block is handed over through LDS
 //    as a SET of two images already in the B-operand layout of the next layer (lane (j, h) writes exactly the bytes lane (j, h) of
-//    the consumer reads): 10 KB of fp16 values and 5 KB of e5m2 residual bytes (PrecH3: x = x16 + r8).  15 KB written + 15-30 KB
-//    read per block and wave instead of 320 KB of weight fragments.  LDS: (2 + 3 + 3) sets + first-layer inputs and fragments = 146 KB.
-//  * One barrier per ROUND, the RE2 / We inputs in rings of three blocks, the RE1 input (written in round i + 3, read in round
-//    i + 4) in a ring of two.  Round r: wave 1 loads the edge indices of its block i = r, the node rows of i-1 and writes the
-//    input features of i-2; the first layer works on i-3, RE1 on i-4, RE2 on i-6, We on i-8.
-//  * A lone wave hides an instruction only in the shadow of an MFMA, and only ~3 of them per MFMA (tools/ubench/mfma_lone.hip: 32-33
-//    cycles per MFMA with <= 3 VALU instructions per MFMA, 39.5 with 4.5).  So the MFMAs are issued from inline asm as (lo.x, hi.x,
-//    hi.r) triples of one accumulator, and after EACH triple runs one "micro-chore" of the previous phase's epilogue: two accumulator
-//    values -> ReLU -> packed fp16 convert -> residual bytes (every fourth: the 16 + 8 byte stores), one piece of a q16 tile
-//    (block maximum, exponent, packed snorm16 converts, stores) or one piece of the input gather, pinned by sched_barrier.  The
-//    accumulators a chore reads were last written four or more MFMAs earlier (asm MFMAs get no hazard nops from the compiler).
-//  * Each accumulator sees lo*x16, hi*x16, hi*r8 by ascending k16-step, so results equal edge_encode_kernel<PrecH3> bit for bit.
+//    the consumer reads): 10 KB of fp16 values and 5 KB of e5m2 residual bytes (PrecH3: x = x16 + r8).  One barrier per ROUND.  Block i:
+//    indices / node rows / features in rounds i .. i + 2 (wave 7), first layer in round i + 3, RE1 i + 4, RE2 i + 5 (its pairs hand the
+//    block over at the start of round i + 6), We i + 7 (its pairs store the rows at the start of round i + 8).  Rings: RE1 and RE2 inputs
+//    two blocks, We input three; LDS 131 KB.
+//  * What a second wave per SIMD buys (tools/ubench/mx_lone.hip, valu_beside_mfma.hip; profiles/r04_edge_ws8_trace.txt): a wave does not
+//    overlap its own VALU work with its own matrix instructions, and while one wave of a SIMD issues MFMAs back to back the other's
+//    instructions take ~10 cycles each (packed fp32 VALU 39: none are used here).  So a wave runs its 30 MFMAs, then its epilogues as plain
+//    code, and the two waves of a SIMD are kept in OPPOSITE halves of their rounds: waves 2-5 start a round with the epilogue of the
+//    accumulators they computed in the previous round, their partners start with their MFMAs.  Until r04 the kernel ran four waves of 512
+//    registers with every epilogue cut into micro-chores pinned into MFMA shadows: 0.72 ms against 0.675 for this one.
+//  * A dependent MFMA issued straight after its predecessor uses the pipe's accumulate path; results of asm MFMAs are not interlocked against
+//    compiler-placed readers (ws_settle), a VALU-written B operand needs two wait states (s_nop 1), and the scaled MFMA reads its eight B
+//    registers over several passes after issue (two register sets by tile parity).
+//  * Each accumulator sees hi.x16 of k16-steps 2t, 2t + 1 and the scaled correction product by ascending input tile t, so results equal
+//    edge_encode_kernel<PrecH3> bit for bit.
 // =====================================================================================================================
 #define AG_WS_IMG 10240          // bytes of one fp16 activation image: [10 k16-steps][64 lanes][8 fp16]
 #define AG_WS_RES 5120           // bytes of its residual image: [10 k16-steps][64 lanes][8 e5m2]
 #define AG_WS_SET (AG_WS_IMG + AG_WS_RES)
 #define AG_WS_IN0 2048           // first-layer input image: 2 k16-steps
 #define AG_WS_SLOTS 3
-#define AG_WS_SLOTS0 2           // ring of the RE1 input: produced in round i + 3, consumed in round i + 4
-#define AG_WS_LAG_F 3
-#define AG_WS_LAG_1 4
-#define AG_WS_LAG_2 6
-#define AG_WS_LAG_3 8
 
 // A (layer, out-tile) unit's A operands: fp16 hi fragments by k16-step, the block-scaled MFMA's operands [e4m3 lo | e4m3 hi] by input tile, and
 // the unit's block scales (lane (i, h): h = 0 the lo scales, h = 1 the hi scales; sc0 = tiles 0..3 by byte, sc1 byte 0 = tile 4)
@@ -1175,96 +1169,7 @@ __device__ __forceinline__ void ws_mfma_mx(f32x16 &acc, const h3_i32x8 &a, const
 #undef AG_MX
 }
 
-// operand rings of a wave, two input tiles deep: per input set the fp16 fragments of the tile's two k16-steps and its sixteen residual bytes
-struct WsRing {
-    bf16x8 xa0[2], xb0[2], r0[2];
-    bf16x8 xa1[2], xb1[2], r1[2];
-};
-
-// One MFMA phase: accumulators [0, NA0) run units W[U0 ..] on the input set at LDS address la0 (this lane's 16 bytes of k16-step 0),
-// accumulators [NA0, NA0 + NA1) the following units on the set at la1; units with index < NACC live in accumulation registers.
-// Per input tile t (32 input columns) an accumulator gets hi.x16 of k16-steps 2t, 2t + 1 and the scaled correction product, issued BACK TO
-// BACK with nothing in between (the dependent MFMA then uses the pipe's accumulate path); the next triple on the same accumulator follows
-// >= 3 MFMAs later.  slot(IC<2p>), slot(IC<2p + 1>) run after triple p = t * NA + k (slot numbers 0 .. 10 NA - 1, in order).
-// With NEXT_NIN > 0 the phase also issues the reads of tile 0 of the NEXT phase (NEXT_NIN input sets at na0 / na1) during its own tile 4,
-// and that phase is instantiated with PRE = true and the ring offset RO = 1 (its tile t sits in ring slot (t + RO) % 2).
-template <int U0, int NA0, int NA1, int NACC, bool PRE, int RO, int NEXT_NIN, int NW, class Slot>
-__device__ __forceinline__ void ws_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NA0 + NA1], WsRing &G, unsigned la0, unsigned la1,
-                                         unsigned na0, unsigned na1, Slot &&slot)
-{
-    constexpr int NIN = NA1 ? 2 : 1, NA = NA0 + NA1;
-    auto issue = [&](auto TT) {
-        constexpr int t = decltype(TT)::value, ri = (t + RO) % 2;
-        if constexpr (t < AG_NT) {
-            lds_read16<(2 * t) * 1024>(G.xa0[ri], la0);
-            lds_read16<(2 * t + 1) * 1024>(G.xb0[ri], la0);
-            lds_read16<AG_WS_IMG + t * 1024>(G.r0[ri], la0);
-            if constexpr (NA1 > 0) {
-                lds_read16<(2 * t) * 1024>(G.xa1[ri], la1);
-                lds_read16<(2 * t + 1) * 1024>(G.xb1[ri], la1);
-                lds_read16<AG_WS_IMG + t * 1024>(G.r1[ri], la1);
-            }
-        } else if constexpr (NEXT_NIN > 0) {
-            lds_read16<0>(G.xa0[ri], na0);
-            lds_read16<1024>(G.xb0[ri], na0);
-            lds_read16<AG_WS_IMG>(G.r0[ri], na0);
-            if constexpr (NEXT_NIN > 1) {
-                lds_read16<0>(G.xa1[ri], na1);
-                lds_read16<1024>(G.xb1[ri], na1);
-                lds_read16<AG_WS_IMG>(G.r1[ri], na1);
-            }
-        }
-    };
-    if constexpr (!PRE) issue(std::integral_constant<int, 0>{});
-    const unsigned one = 0x7f7f7f7fu;      // E8M0 127 = 2^0: the activations' bytes are plain e5m2 numbers
-    // The scaled MFMA reads its eight B registers over several passes AFTER it has issued: a permute that re-uses them for the next tile a
-    // dozen instructions later corrupted the residual half of the LAST accumulator's operand (found as a rare 3e-5 relative difference from the
-    // streaming kernel).  So the B operands alternate between two register sets by tile parity, each kept reserved until the end of the NEXT tile.
-    h3_i32x8 Bq0[2], Bq1[2];
-    static_for<0, AG_NT>([&](auto TT) {
-        constexpr int t = decltype(TT)::value, ri = (t + RO) % 2;
-        issue(std::integral_constant<int, t + 1>{});
-        constexpr int after = (t + 1 < AG_NT) ? NIN : NEXT_NIN;      // input sets whose (three) reads were issued after tile t's
-        ws_wait3<3 * after>(G.xa0[ri], G.xb0[ri], G.r0[ri]);
-        if constexpr (NA1 > 0) ws_wait3<3 * after>(G.xa1[ri], G.xb1[ri], G.r1[ri]);
-        const bf16x8 xa0 = G.xa0[ri], xb0 = G.xb0[ri], xa1 = NA1 > 0 ? G.xa1[ri] : G.xa0[ri], xb1 = NA1 > 0 ? G.xb1[ri] : G.xb0[ri];
-        h3_i32x8 &B0 = Bq0[t & 1], &B1 = NA1 > 0 ? Bq1[t & 1] : Bq0[t & 1];
-        B0 = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa0), __builtin_bit_cast(h3_u32x4, xb0)), __builtin_bit_cast(h3_u32x4, G.r0[ri]));
-        if constexpr (NA1 > 0) B1 = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa1), __builtin_bit_cast(h3_u32x4, xb1)), __builtin_bit_cast(h3_u32x4, G.r1[ri]));
-        // An MFMA that reads a register a VALU instruction has just written needs two wait states (the compiler inserts them for builtin
-        // MFMAs; the hazard recogniser does not look inside asm): the byte permutes are pinned here, ahead of the tile's first MFMA.
-        if constexpr (NA1 > 0) asm volatile("s_nop 1" : "+v"(B0), "+v"(B1)); else asm volatile("s_nop 1" : "+v"(B0));
-        // Issue order (measured with the round trace, tools/trace_ws.py: a lone wave issues in order, a dependent MFMA waits for its
-        // predecessor's write-back — ~50 cycles after an fp16 MFMA, ~80 after a scaled one — and a lone chore is one dependent VALU chain of
-        // ~70 cycles): the fp16 MFMAs of ALL accumulators first, chain by chain interleaved, so that no MFMA waits for the one issued just
-        // before it; then one scaled MFMA per accumulator with TWO chores behind it — two independent VALU chains the compiler interleaves
-        // inside the scaled MFMA's 64-cycle shadow.  Triple-by-triple issue measured 208 cycles per triple, pipe time 128.
-        static_for<0, NA>([&](auto KK) {
-            constexpr int k = decltype(KK)::value;
-            ws_mfma<(U0 + k < NACC), (t == 0)>(acc[k], W[U0 + k].hi[2 * t], k < NA0 ? xa0 : xa1);
-        });
-        static_for<0, NA>([&](auto KK) {
-            constexpr int k = decltype(KK)::value;
-            ws_mfma<(U0 + k < NACC), false>(acc[k], W[U0 + k].hi[2 * t + 1], k < NA0 ? xb0 : xb1);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, NA>([&](auto KK) {
-            constexpr int k = decltype(KK)::value;
-            const WsUnit &U = W[U0 + k];
-            ws_mfma_mx<(U0 + k < NACC), (t & 3)>(acc[k], U.mx[t], k < NA0 ? B0 : B1, t < 4 ? U.sc0 : U.sc1, one);
-            __builtin_amdgcn_sched_barrier(0);
-            slot(std::integral_constant<int, 2 * (t * NA + k)>{});
-            slot(std::integral_constant<int, 2 * (t * NA + k) + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (t > 0) {      // the previous tile's operands are released only now
-            if constexpr (NA1 > 0) asm volatile("" :: "v"(Bq0[(t - 1) & 1]), "v"(Bq1[(t - 1) & 1])); else asm volatile("" :: "v"(Bq0[(t - 1) & 1]));
-        }
-    });
-    if constexpr (NA1 > 0) asm volatile("" :: "v"(Bq0[(AG_NT - 1) & 1]), "v"(Bq1[(AG_NT - 1) & 1])); else asm volatile("" :: "v"(Bq0[(AG_NT - 1) & 1]));
-}
-
-// Epilogue micro-chores of the hidden layers.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values):
+// Epilogue of the hidden layers in eight pieces.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values):
 // ReLU, packed fp16 convert, largest-pattern tracking, the two residual bytes (h3_pair); the fourth dword stores the consumer's 16 bytes
 // of k16-step 2T + S (bias column: feature 150 := 1.0) and its 8 residual bytes (residual image: [5 input tiles][64 lanes][16 bytes]).
 struct WsEpi { ws_u32x4 H; int R0, R1; unsigned bad; };
@@ -1374,258 +1279,23 @@ __device__ __forceinline__ void ws_first_layer(f32x16 (&accF)[NT], unsigned lin,
     });
 }
 
-__global__ __launch_bounds__(256, 1) void edge_encode_ws_kernel(AgWeights w, AgFwdArgs a)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char s_act0[AG_WS_SLOTS0][AG_WS_SET];    // input sets of RE1 (ring of two blocks)
-    __shared__ __attribute__((aligned(16))) unsigned char s_act12[2][AG_WS_SLOTS][AG_WS_SET]; // ... of RE2 and We (rings of three)
-    __shared__ __attribute__((aligned(16))) unsigned char s_in0[AG_WS_SLOTS][AG_WS_IN0];      // first-layer inputs
-    __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn];
-    if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
-    const int nblk = (E + 31) / 32;
-    if ((int)blockIdx.x >= nblk) return;
-    const int n_i = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup: blockIdx + i * gridDim
-    const int rounds = n_i + AG_WS_LAG_3 + 2;
-    const float4 *ws = w.edge_encode_h2;
-    for (int i = tid; i < AG_CHUNK_F4; i += 256) s_wf[i] = ws[i];
-    for (int i = tid; i < (int)(sizeof(s_act0) / 16); i += 256) reinterpret_cast<float4 *>(&s_act0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < (int)(sizeof(s_act12) / 16); i += 256) reinterpret_cast<float4 *>(&s_act12[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 256) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
-    auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
-    auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
-    // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i
-    auto img = [&](int layer, int i) -> lds_u8 * {
-        return (lds_u8 *)(layer == 0 ? &s_act0[(i + 12) % AG_WS_SLOTS0][lane * 16] : &s_act12[layer - 1][slot_of(i)][lane * 16]);
-    };
-    auto block_ok = [&](int i) { return i >= 0 && i < n_i; };
-    auto eterm_row = [&](int i) {
-        const size_t e = (block_ok(i) ? (size_t)gblock(i) * 32 : e_pad) + j;
-        return reinterpret_cast<unsigned char *>(a.eterm) + e * (2 * AG_FP);
-    };
-    WsUnit W[4];
-    WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
-    WsRing G;
-    const uint32_t *wsc = w.edge_scale_h3;      // block scales of unit k (stream chunk 1 + k): wsc + 128 k
-    // accumulators start at zero: the first rounds' chores convert them before any MFMA has written them
-    auto zero = [](auto &arr) {
-        for (auto &v : arr)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = 0.0f;
-    };
-
-    if (wave == 0) {
-        // ---------------------------------------------------------------- first layer tiles 0-2, RE1 tiles 0-2
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + k) * AG_CHUNK_F4, wsc + (size_t)((1 + k) - 1) * 128, lane);
-        __syncthreads();
-        f32x16 accF[3], accP[3];
-        zero(accF); zero(accP);
-        const unsigned wf = lds_addr_of(s_wf) + lane * 16;
-#pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-            const int i0 = r - AG_WS_LAG_F, i1 = r - AG_WS_LAG_1;
-            lds_u8 *outF = img(0, i0), *outPp = img(1, i1 - 1);
-            // first layer of block i0, tiles 0-2 (12 MFMAs);  shadow: finish RE1 tiles 0-2 of the previous block (24 micro-chores, in pairs)
-            ws_first_layer<0, 3>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, [&](auto MM) {
-                constexpr int m = decltype(MM)::value;                     // 0..11
-                ws_act_micro<(2 * m) / 8, (2 * m) % 8>(accP[(2 * m) / 8], Ep, outPp, h);
-                ws_act_micro<(2 * m + 1) / 8, (2 * m + 1) % 8>(accP[(2 * m + 1) / 8], Ep, outPp, h);
-            });
-            const unsigned la = lds_addr3(img(0, i1));
-            ws_phase<0, 3, 0, 3, false, 0, 0>(W, accP, G, la, la, la, la, [&](auto PP) {        // RE1 tiles 0-2;  shadow: finish first-layer tiles 0-2 (24 micro-chores in 30 slots)
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 24) ws_act_micro<p / 8, p % 8>(accF[p / 8], Ep, outF, h);
-            });
-            ws_round_barrier();
-        }
-    } else if (wave == 1) {
-        // ---------------------------------------------------------------- RE1 tiles 3-4, RE2 tiles 0-1, per-edge input gather
-#pragma unroll
-        for (int k = 0; k < 2; ++k) ws_load_unit<true>(W[k], ws + (size_t)(1 + 3 + k) * AG_CHUNK_F4, wsc + (size_t)((1 + 3 + k) - 1) * 128, lane);
-        ws_load_unit<true>(W[2], ws + (size_t)(6 + 0) * AG_CHUNK_F4, wsc + (size_t)((6 + 0) - 1) * 128, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(6 + 1) * AG_CHUNK_F4, wsc + (size_t)((6 + 1) - 1) * 128, lane);
-        __syncthreads();
-        f32x16 accP[2], accQ[2];
-        zero(accP); zero(accQ);
-        // The gather of one block's inputs (model.py:220-253) is cut into pieces of a few instructions, one per MFMA-triple slot,
-        // three blocks in flight: edge indices (this round) -> the two 64-byte node rows (next round) -> features (the round after).
-        int er = 0, es = 0;                // indices of block r (loaded in round r, used in round r + 1)
-        float4 R[4], S[4];                 // receiver / sender rows of block r - 1 (loaded in round r, used in round r + 1)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) R[q] = S[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float feat[24];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        auto pk = [](float x0, float x1) { const f32x2 v = {x0, x1}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2)); };
-        ws_u32x4 X1 = {0u, 0u, 0u, 0u};      // k16-step 1 of the block's first-layer input image
-        const float4 *tab = reinterpret_cast<const float4 *>(a.edge_node_tab);
-#pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-            const int i1 = r - AG_WS_LAG_1, i2 = r - AG_WS_LAG_2;
-            const unsigned la1 = lds_addr3(img(0, i1)), la2 = lds_addr3(img(1, i2));
-            lds_u8 *out1 = img(1, i1), *out2p = img(2, i2 - 1);
-            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la1, la1, la2, la2, [&](auto PP) {      // RE1 tiles 3, 4;  shadow: finish RE2 tiles 0, 1 of the previous block
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<p / 8, p % 8>(accQ[p / 8], Ep, out2p, h);
-                // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1]
-                if constexpr (p == 14) {
-                    feat[0] = R[0].x; feat[1] = R[0].y; feat[2] = S[0].x; feat[3] = S[0].y; feat[4] = fabsf(R[0].z - S[0].z); feat[AG_EDGE_IN] = 1.0f;
-                    feat[5] = R[1].x - S[1].x; feat[6] = R[1].y - S[1].y; feat[7] = R[1].z - S[1].z; feat[8] = R[1].w - S[1].w;
-                }
-                if constexpr (p == 15) {
-                    feat[9] = R[2].x - S[2].x; feat[10] = R[2].y - S[2].y; feat[11] = R[2].z - S[2].z; feat[12] = R[2].w - S[2].w;
-                    feat[13] = R[3].x - S[3].x; feat[14] = R[3].y - S[3].y; feat[15] = R[3].z - S[3].z; feat[16] = R[3].w - S[3].w;
-                }
-                // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (slot 16: feature 16, 17: the bias
-                // 1.0, 18..29: the fp16 residuals of features 5..16, f16_residual; the same values in the same slots as edge_encode_kernel<PrecH3>)
-                if constexpr (p == 16) {
-                    ws_u32x4 X;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2)
-                            X[2 * q + c2] = pk(h ? feat[8 * q + 4 + 2 * c2] : feat[8 * q + 2 * c2], h ? feat[8 * q + 5 + 2 * c2] : feat[8 * q + 1 + 2 * c2]);
-                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16]) = X;
-                }
-                if constexpr (p == 17) {        // slots 16, 17 | 20, 21 and 18, 19 | 22, 23   (h = 0 | h = 1)
-                    X1[0] = h ? pk(f16_residual(feat[7]), f16_residual(feat[8])) : pk(feat[16], feat[AG_EDGE_IN]);
-                    X1[1] = h ? pk(f16_residual(feat[9]), f16_residual(feat[10])) : pk(f16_residual(feat[5]), f16_residual(feat[6]));
-                }
-                if constexpr (p == 18) {        // slots 24, 25 | 28, 29 and 26, 27 | 30, 31 (slots 30, 31 stay zero)
-                    X1[2] = h ? pk(f16_residual(feat[15]), f16_residual(feat[16])) : pk(f16_residual(feat[11]), f16_residual(feat[12]));
-                    X1[3] = h ? 0u : pk(f16_residual(feat[13]), f16_residual(feat[14]));
-                    *reinterpret_cast<ws_u32x4 *>(&s_in0[slot_of(r - 2)][lane * 16 + 1024]) = X1;
-                }
-            });
-            static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
-            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la2, la2, la2, la2, [&](auto PP) {      // RE2 tiles 0, 1;  shadow: finish RE1 tiles 3, 4
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accP[p / 8], Ep, out1, h);
-                // node rows of block r - 1 (indices loaded last round): 2 x 64 bytes, one 16-byte load per piece
-                if constexpr (p >= 6 && p < 14) {
-                    constexpr int q = (p - 6) & 3;
-                    if constexpr ((p - 6) < 4) R[q] = tab[(unsigned)er * 4u + q];
-                    else S[q] = tab[(unsigned)es * 4u + q];
-                }
-                if constexpr (p == 18) {                                // edge indices of block r
-                    const int e = (r < n_i ? gblock(r) : 0) * 32 + j;
-                    const bool valid = r < n_i && e < E;
-                    er = valid ? a.edge_recv[e] : 0;
-                    es = valid ? a.edge_send[e] : 0;
-                }
-            });
-            ws_round_barrier();
-        }
-    } else if (wave == 2) {
-        // ---------------------------------------------------------------- RE2 tiles 2-4, We tile 0
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(6 + 2 + k) * AG_CHUNK_F4, wsc + (size_t)((6 + 2 + k) - 1) * 128, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(11 + 0) * AG_CHUNK_F4, wsc + (size_t)((11 + 0) - 1) * 128, lane);
-        __syncthreads();
-        f32x16 accP[2], accQ[2];
-        zero(accP); zero(accQ);
-        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
-#pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-            const int i2 = r - AG_WS_LAG_2, i3 = r - AG_WS_LAG_3;
-            const unsigned la2 = lds_addr3(img(1, i2)), la3 = lds_addr3(img(2, i3));
-            lds_u8 *out2 = img(2, i2), *out2p = img(2, i2 - 1);
-            unsigned char *rowp = eterm_row(i3 - 1);
-            ws_phase<0, 2, 0, 3, false, 0, 2>(W, accP, G, la2, la2, la2, la3, [&](auto PP) {      // RE2 tiles 2, 3;  shadow: finish RE2 tile 4 and We tile 0 of the previous blocks
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 8) ws_act_micro<4, p>(accQ[0], Ep, out2p, h);
-                if constexpr (p >= 8 && p < 15) ws_q16_chore<0, p - 8>(accQ[1], Q, rowp, h);
-            });
-            ws_phase<2, 1, 1, 3, true, 1, 0>(W, accQ, G, la2, la3, la2, la3, [&](auto PP) {      // RE2 tile 4 + We tile 0
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<2 + p / 8, p % 8>(accP[p / 8], Ep, out2, h);
-            });
-            ws_round_barrier();
-        }
-        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
-    } else {
-        // ---------------------------------------------------------------- first layer tiles 3-4, We tiles 1-4
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ws_load_unit<true>(W[k], ws + (size_t)(11 + 1 + k) * AG_CHUNK_F4, wsc + (size_t)((11 + 1 + k) - 1) * 128, lane);
-        ws_load_unit<false>(W[3], ws + (size_t)(11 + 4) * AG_CHUNK_F4, wsc + (size_t)((11 + 4) - 1) * 128, lane);
-        __syncthreads();
-        f32x16 accF[2], accP[2], accQ[2];
-        zero(accF); zero(accP); zero(accQ);
-        WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
-        const unsigned wf = lds_addr_of(s_wf) + lane * 16;
-#pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-            const int i0 = r - AG_WS_LAG_F, i3 = r - AG_WS_LAG_3;
-            lds_u8 *outF = img(0, i0);
-            unsigned char *row = eterm_row(i3), *rowp = eterm_row(i3 - 1);
-            // first layer of block i0, tiles 3-4 (8 MFMAs);  shadow: store We tiles 3, 4 of the previous block (14 chores, in pairs)
-            ws_first_layer<3, 2>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, [&](auto MM) {
-                constexpr int m = decltype(MM)::value;                     // 0..7
-                if constexpr (2 * m < 14) ws_q16_chore<3 + (2 * m) / 7, (2 * m) % 7>(accQ[(2 * m) / 7], Q, rowp, h);
-                if constexpr (2 * m + 1 < 14) ws_q16_chore<3 + (2 * m + 1) / 7, (2 * m + 1) % 7>(accQ[(2 * m + 1) / 7], Q, rowp, h);
-            });
-            const unsigned la3 = lds_addr3(img(2, i3));
-            ws_phase<0, 2, 0, 3, false, 0, 1>(W, accP, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 1, 2;  shadow: finish first-layer tiles 3, 4 (16 micro-chores)
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 16) ws_act_micro<3 + p / 8, p % 8>(accF[p / 8], Ep, outF, h);
-            });
-            ws_phase<2, 2, 0, 3, true, 1, 0>(W, accQ, G, la3, la3, la3, la3, [&](auto PP) {      // We tiles 3, 4;  shadow: store We tiles 1, 2
-                constexpr int p = decltype(PP)::value;
-                if constexpr (p < 7) ws_q16_chore<1, p>(accP[0], Q, row, h);
-                if constexpr (p >= 10 && p < 17) ws_q16_chore<2, p - 10>(accP[1], Q, row, h);
-            });
-            ws_round_barrier();
-        }
-        if (Q.nonfinite && a.status) atomicOr(a.status, 1);
-    }
-    h3_report(Ep.bad, a.status);
-}
-
-// =====================================================================================================================
-// The same dataflow on EIGHT waves (two per SIMD, 256 registers each): edge_encode_ws8_kernel.
-//
-// tools/ubench/mx_lone.hip: a lone wave does not overlap its own VALU work with its own matrix instructions (a triple of 128 pipe cycles
-// followed by 18 VALU instructions takes 183), but a SECOND wave on the SIMD hides them completely (257 cycles for both waves' triple + 18
-// VALU: the pipe never idles).  With four waves of 512 registers every epilogue instruction of edge_encode_ws_kernel is paid in matrix-pipe idle
-// time (round 5 600 cycles for 2 560 of pipe work); here a wave keeps TWO units (160 accumulation registers), runs their 30 matrix instructions,
-// then their epilogues as plain code — no micro-chores, no deferred epilogues — while its SIMD partner is in the other half of its round:
-//     wave 0, 1: RE1 tiles {0,1}, {2,3}      wave 2, 3: RE2 tiles {0,1}, {2,3}      wave 4, 5: first-layer tile 0 / 1 + We tiles {0,1}, {2,3}
-//     wave 6: RE1 tile 4, RE2 tile 4         wave 7: input gather, first-layer tiles 2-4, We tile 4
-// (waves w and w + 4 share a SIMD: 2 560-2 820 pipe cycles per SIMD and round).  Block i: gathered in rounds i .. i + 2, first layer in round
-// i + 3, RE1 i + 4, RE2 i + 5, We i + 6; every set ring is two blocks deep, one barrier per round; LDS 116 KB.
-// Every accumulator sees the same products in the same order as in the other two edge kernels: same bits.
-// =====================================================================================================================
-#define AG_WS8_LAG_F 3
-#define AG_WS8_LAG_1 4
-#define AG_WS8_LAG_2 5
-#define AG_WS8_LAG_3 6
+#define AG_WS_LAG_F 3
+#define AG_WS_LAG_1 4
+#define AG_WS_LAG_2 5
+#define AG_WS_LAG_3 7      // the RE2 pairs hand their block over at the start of the NEXT round
 // An asm MFMA's result is not interlocked against the VALU instructions the compiler places after it: 16 passes + 4 states for the scaled one
-__device__ __forceinline__ void ws8_settle(f32x16 &a) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a)); }
-__device__ __forceinline__ void ws8_settle(f32x16 &a, f32x16 &b) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void ws8_settle(f32x16 &a, f32x16 &b, f32x16 &c) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void ws_settle(f32x16 &a) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a)); }
+__device__ __forceinline__ void ws_settle(f32x16 &a, f32x16 &b) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void ws_settle(f32x16 &a, f32x16 &b, f32x16 &c) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c)); }
 // One MFMA phase of the eight-wave kernel: accumulators 0 .. NA-1 run units W[0 .. NA-1] on ONE input set (la: this lane's 16 bytes of k16-step 0).
 // The compiler splits a 256-register wave into 128 + 128: a wave's first unit and the fp16 half of its second live in accumulation registers
 // (NACC2 half-units: fp16 fragments of unit k = half-unit 2k, its scaled-MFMA operands = half-unit 2k + 1), the rest in architectural ones.
 // No operand ring: the partner wave's matrix work covers the LDS latency.  The next tile's reads are issued after the fp16 MFMAs that read the
 // current fragments and land during the scaled MFMAs; the scaled MFMA's B operand (read over several passes after issue) alternates between two
 // register sets by tile parity.
-#ifdef AG_WS_TRACE
-__device__ unsigned long long g_ws8_tiles[8 * 16 * 8];
-#define WS8_TILE(k) do { if (tr >= 0 && lane_ == 0) g_ws8_tiles[tr * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define WS8_TILE(k)
-#endif
 template <int NA, int NACC2, int U0 = 0, int NW, int NACCS>
-__device__ __forceinline__ void ws8_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NACCS], unsigned la, int tr = -1)
+__device__ __forceinline__ void ws_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NACCS], unsigned la)
 {
-    const int lane_ = threadIdx.x & 63; (void)lane_;
-    WS8_TILE(0);
     bf16x8 xa, xb, r;
     lds_read16<0>(xa, la);
     lds_read16<1024>(xb, la);
@@ -1655,30 +1325,23 @@ __device__ __forceinline__ void ws8_phase(const WsUnit (&W)[NW], f32x16 (&acc)[N
             ws_mfma_mx<(2 * (U0 + k) + 1 < NACC2), (t & 3)>(acc[U0 + k], W[U0 + k].mx[t], B, t < 4 ? W[U0 + k].sc0 : W[U0 + k].sc1, one);
         });
         if constexpr (t > 0) asm volatile("" :: "v"(Bq[(t - 1) & 1]));      // the previous tile's operand is released only now
-        WS8_TILE(t + 1);
     });
     asm volatile("" :: "v"(Bq[(AG_NT - 1) & 1]));
 }
 template <int T>
-__device__ __forceinline__ void ws8_hidden_tile(const f32x16 &acc, WsEpi &E, lds_u8 *set_lane, int h)
+__device__ __forceinline__ void ws_hidden_tile(const f32x16 &acc, WsEpi &E, lds_u8 *set_lane, int h)
 {
     static_for<0, 8>([&](auto MM) { ws_act_micro<T, decltype(MM)::value>(acc, E, set_lane, h); });
 }
 template <int T>
-__device__ __forceinline__ void ws8_table_tile(const f32x16 &acc, WsQ16 &Q, unsigned char *row, int h)
+__device__ __forceinline__ void ws_table_tile(const f32x16 &acc, WsQ16 &Q, unsigned char *row, int h)
 {
     static_for<0, 7>([&](auto CC) { ws_q16_chore<T, decltype(CC)::value>(acc, Q, row, h); });
 }
 
-#ifdef AG_WS_TRACE      // TEMPORARY: s_memtime stamps of workgroup 3, rounds 100..115 (tools/trace_ws8.py)
-__device__ unsigned long long g_ws8_trace[8 * 16 * 8 + 8];
-#define WS8_T(k) do { if (blockIdx.x == 3 && r >= 100 && r < 116 && lane == 0) g_ws8_trace[(wave * 16 + (r - 100)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define WS8_T(k)
-#endif
-__global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, AgFwdArgs a)
+__global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgFwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_act[3][2][AG_WS_SET];             // input sets of RE1, RE2, We: rings of two blocks
+    __shared__ __attribute__((aligned(16))) unsigned char s_act[7][AG_WS_SET];                // input sets of RE1, RE2 (rings of two blocks), We (ring of three)
     __shared__ __attribute__((aligned(16))) unsigned char s_in0[AG_WS_SLOTS][AG_WS_IN0];      // first-layer inputs
     __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -1689,24 +1352,21 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
     const int nblk = (E + 31) / 32;
     if ((int)blockIdx.x >= nblk) return;
     const int n_i = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup: blockIdx + i * gridDim
-    const int rounds = n_i + AG_WS8_LAG_3 + 1;      // + 1: the We pairs store a block's rows at the start of the next round
+    const int rounds = n_i + AG_WS_LAG_3 + 1;      // + 1: the We pairs store a block's rows at the start of the next round
     const float4 *ws = w.edge_encode_h2;
     for (int i = tid; i < AG_CHUNK_F4; i += 512) s_wf[i] = ws[i];
-    for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 512) reinterpret_cast<float4 *>(&s_act[0][0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 512) reinterpret_cast<float4 *>(&s_act[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 512) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
     auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
     auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
     // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i (i >= -8)
-    auto img = [&](int layer, int i) -> lds_u8 * { return (lds_u8 *)&s_act[layer][(i + 8) & 1][lane * 16]; };
+    auto img = [&](int layer, int i) -> lds_u8 * { return (lds_u8 *)&s_act[layer < 2 ? 2 * layer + ((i + 8) & 1) : 4 + (i + 9) % 3][lane * 16]; };
     auto eterm_row = [&](int i) {
         const size_t e = ((i >= 0 && i < n_i) ? (size_t)gblock(i) * 32 : e_pad) + j;
         return reinterpret_cast<unsigned char *>(a.eterm) + e * (2 * AG_FP);
     };
     WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
-#ifdef AG_WS_TRACE
-    if (blockIdx.x == 3 && lane == 0) g_ws8_trace[8 * 16 * 8 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-#endif
     const uint32_t *wsc = w.edge_scale_h3;      // block scales of unit k (stream chunk 1 + k): wsc + 128 k
     auto load_unit = [&](WsUnit &U, int chunk) { ws_load_unit<true, true>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };
     auto load_unit2 = [&](WsUnit &U, int chunk) { ws_load_unit<true, false>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };
@@ -1714,39 +1374,40 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
     const unsigned wf = lds_addr_of(s_wf) + lane * 16;
 
     // hidden layer L (1: RE1, 2: RE2), out-tiles T0 and T0 + 1; then first-layer tile TF (-1: none)
-    auto hidden_pair = [&](auto LL, auto TT, auto FF) {
+    auto hidden_pair = [&](auto LL, auto TT, auto FF, auto DD) {
         constexpr int L = decltype(LL)::value, T0 = decltype(TT)::value, TF = decltype(FF)::value;
+        constexpr bool DEFER = decltype(DD)::value;      // the round starts with the PREVIOUS round's epilogue (the SIMD partner starts with its MFMAs)
         WsUnit W[2];
         load_unit(W[0], 1 + 5 * (L - 1) + T0);
         load_unit2(W[1], 2 + 5 * (L - 1) + T0);
         __syncthreads();
         f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[0][q] = acc[1][q] = 0.0f;
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            const int i = r - (AG_WS8_LAG_F + L);
+            const int i = r - (AG_WS_LAG_F + L);
+            if constexpr (DEFER) {
+                lds_u8 *outp = img(L, i - 1);
+                ws_hidden_tile<T0>(acc[0], Ep, outp, h);
+                ws_hidden_tile<T0 + 1>(acc[1], Ep, outp, h);
+            }
             const unsigned la = lds_addr3(img(L - 1, i));
-            lds_u8 *out = img(L, i);
-            WS8_T(0);
-            ws8_phase<2, 3>(W, acc, la, (blockIdx.x == 3 && r >= 100 && r < 116) ? wave * 16 + (r - 100) : -1);
-            WS8_T(3);
-            ws8_settle(acc[0], acc[1]);
-            ws8_hidden_tile<T0>(acc[0], Ep, out, h);
-            ws8_hidden_tile<T0 + 1>(acc[1], Ep, out, h);
-            WS8_T(4);
+            ws_phase<2, 3>(W, acc, la);
+            ws_settle(acc[0], acc[1]);
+            if constexpr (!DEFER) {
+                lds_u8 *out = img(L, i);
+                ws_hidden_tile<T0>(acc[0], Ep, out, h);
+                ws_hidden_tile<T0 + 1>(acc[1], Ep, out, h);
+            }
             if constexpr (TF >= 0) {
-                const int i0 = r - AG_WS8_LAG_F;
+                const int i0 = r - AG_WS_LAG_F;
                 f32x16 accF[1];
                 ws_first_layer<TF, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
-                WS8_T(5);
-                ws8_settle(accF[0]);
-                ws8_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
-                WS8_T(6);
+                ws_settle(accF[0]);
+                ws_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
             }
-#ifdef AG_WS_SLEEP
-            __builtin_amdgcn_s_sleep(AG_WS_SLEEP);
-#endif
             ws_round_barrier();
-            WS8_T(7);
         }
     };
     // We tiles T0 and T0 + 1 and first-layer tile TF.  The round STARTS with the previous round's table epilogue (the SIMD partner starts with its
@@ -1763,38 +1424,29 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
         WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            const int i0 = r - AG_WS8_LAG_F, i3 = r - AG_WS8_LAG_3;
-            WS8_T(0);
+            const int i0 = r - AG_WS_LAG_F, i3 = r - AG_WS_LAG_3;
             unsigned char *rowp = eterm_row(i3 - 1);
-            ws8_table_tile<T0>(acc[0], Q, rowp, h);
-            ws8_table_tile<T0 + 1>(acc[1], Q, rowp, h);
-            WS8_T(1);
-            ws_first_layer<TF, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
-            WS8_T(2);
-            ws8_settle(accF[0]);
-            ws8_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
-            WS8_T(3);
+            ws_table_tile<T0>(acc[0], Q, rowp, h);
+            ws_table_tile<T0 + 1>(acc[1], Q, rowp, h);
+            if constexpr (TF >= 0) {
+                ws_first_layer<TF, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
+                ws_settle(accF[0]);
+                ws_hidden_tile<TF>(accF[0], Ep, img(0, i0), h);
+            }
             const unsigned la = lds_addr3(img(2, i3));
-#ifdef AG_WS_SPLIT
-            ws8_phase<1, 3, 0>(W, acc, la);
-            ws8_phase<1, 3, 1>(W, acc, la);
-#else
-            ws8_phase<2, 3>(W, acc, la, (blockIdx.x == 3 && r >= 100 && r < 116) ? wave * 16 + (r - 100) : -1);
-#endif
-            WS8_T(4);
-            ws8_settle(acc[0], acc[1]);
+            ws_phase<2, 3>(W, acc, la);
+            ws_settle(acc[0], acc[1]);
             ws_round_barrier();
-            WS8_T(7);
         }
         if (Q.nonfinite && a.status) atomicOr(a.status, 1);
     };
 
-    if (wave == 0) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
-    else if (wave == 1) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, -1>{});
-    else if (wave == 2) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
-    else if (wave == 3) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-    else if (wave == 4) table_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    else if (wave == 5) table_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    if (wave == 0) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{});
+    else if (wave == 1) hidden_pair(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::false_type{});
+    else if (wave == 2) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
+    else if (wave == 3) hidden_pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::true_type{});
+    else if (wave == 4) table_pair(std::integral_constant<int, -1>{}, std::integral_constant<int, 0>{});
+    else if (wave == 5) table_pair(std::integral_constant<int, -1>{}, std::integral_constant<int, 2>{});
     else if (wave == 6) {
         // ---------------------------------------------------------------- RE1 tile 4 and RE2 tile 4: two input sets, one after the other
         WsUnit W[1], W1[1];
@@ -1804,28 +1456,22 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
         f32x16 accA[1], accB[1];
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            const int i1 = r - AG_WS8_LAG_1, i2 = r - AG_WS8_LAG_2;
+            const int i1 = r - AG_WS_LAG_1, i2 = r - AG_WS_LAG_2;
             const unsigned la1 = lds_addr3(img(0, i1)), la2 = lds_addr3(img(1, i2));
-            WS8_T(0);
-            ws8_phase<1, 2>(W, accA, la1);
-            WS8_T(1);
-            ws8_settle(accA[0]);
-            ws8_hidden_tile<4>(accA[0], Ep, img(1, i1), h);
-            WS8_T(2);
-            ws8_phase<1, 1>(W1, accB, la2);
-            WS8_T(3);
-            ws8_settle(accB[0]);
-            ws8_hidden_tile<4>(accB[0], Ep, img(2, i2), h);
-            WS8_T(4);
+            ws_phase<1, 2>(W, accA, la1);
+            ws_settle(accA[0]);
+            ws_hidden_tile<4>(accA[0], Ep, img(1, i1), h);
+            ws_phase<1, 1>(W1, accB, la2);
+            ws_settle(accB[0]);
+            ws_hidden_tile<4>(accB[0], Ep, img(2, i2), h);
             ws_round_barrier();
-            WS8_T(7);
         }
     } else {
         // ---------------------------------------------------------------- per-edge input gather, first-layer tiles 2-4, We tile 4
         WsUnit W[1];
         load_unit(W[0], 11 + 4);
         __syncthreads();
-        f32x16 accF[2], acc[1];
+        f32x16 accF[1], acc[1];
         WsQ16 Q{0u, AG_Q16_EB_MIN, 0, {0u, 0u, 0u, 0u}, 0u};
         // three blocks in flight: edge indices (this round) -> the two 64-byte node rows (next round) -> features (the round after)
         int er = 0, es = 0;                // indices of block r (loaded in round r, used in round r + 1)
@@ -1839,8 +1485,13 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
         static_assert(AG_NHIS == 4 && AG_EDGE_IN == 17, "edge_node_tab rows and the feature pieces are laid out for four history frames");
 #pragma unroll 1
         for (int r = 0; r < rounds; ++r) {
-            const int i0 = r - AG_WS8_LAG_F, i3 = r - AG_WS8_LAG_3;
-            WS8_T(0);
+            const int i0 = r - AG_WS_LAG_F, i3 = r - AG_WS_LAG_3;
+            {   // We tile 4 first: the SIMD partner (an RE2 pair) starts its round with an epilogue
+                const unsigned la = lds_addr3(img(2, i3));
+                ws_phase<1, 2>(W, acc, la);
+                ws_settle(acc[0]);
+                ws_table_tile<4>(acc[0], Q, eterm_row(i3), h);
+            }
             {   // features of block r - 2 from the rows loaded last round: [attrs_r | attrs_s | |g_r - g_s| | row_r[4:16] - row_s[4:16] | 1];
                 // lane half h keeps slots 8q + 4h + c -> B-operand image of k16-step 0 (features 0..15) and 1 (slot 16: feature 16, 17: the bias
                 // 1.0, 18..29: the fp16 residuals of features 5..16, f16_residual; the same values in the same slots as edge_encode_kernel<PrecH3>)
@@ -1873,37 +1524,15 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws8_kernel(AgWeights w, Ag
                 er = valid ? a.edge_recv[e] : 0;
                 es = valid ? a.edge_send[e] : 0;
             }
-            WS8_T(5);
-            ws_first_layer<2, 2>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
-            WS8_T(1);
-            ws8_settle(accF[0], accF[1]);
-            lds_u8 *outF = img(0, i0);
-            ws8_hidden_tile<2>(accF[0], Ep, outF, h);
-            ws8_hidden_tile<3>(accF[1], Ep, outF, h);
-            WS8_T(2);
-            const unsigned la = lds_addr3(img(2, i3));
-            ws8_phase<1, 2>(W, acc, la);
-            WS8_T(3);
-            ws8_settle(acc[0]);
-            ws8_table_tile<4>(acc[0], Q, eterm_row(i3), h);
-            WS8_T(4);
+            ws_first_layer<4, 1>(accF, lds_addr_of(&s_in0[slot_of(i0)][lane * 16]), wf, noop);
+            ws_settle(accF[0]);
+            ws_hidden_tile<4>(accF[0], Ep, img(0, i0), h);
             ws_round_barrier();
-            WS8_T(7);
         }
         if (Q.nonfinite && a.status) atomicOr(a.status, 1);
     }
     h3_report(Ep.bad, a.status);
 }
-#ifdef AG_WS_TRACE
-extern "C" __attribute__((visibility("default"))) int ag_ws_trace_read(unsigned long long *dst)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws8_trace), sizeof(g_ws8_trace));
-}
-extern "C" __attribute__((visibility("default"))) int ag_ws_tiles_read(unsigned long long *dst)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws8_tiles), sizeof(g_ws8_tiles));
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // One propagation round at node level: fused segment reduce (aggregate_rows) or a pre-computed `agg` table,
@@ -2253,9 +1882,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
             hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
-            const dim3 gws(blocks < slots ? blocks : (slots > 0 ? slots : 1));
-            if (a.edge_ws == 2) hipLaunchKernelGGL(edge_encode_ws8_kernel, gws, dim3(512), 0, s, w, a);     // eight waves, two per SIMD
-            else hipLaunchKernelGGL(edge_encode_ws_kernel, gws, dim3(256), 0, s, w, a);                     // four waves, whatever AG_MLP_THREADS is
+            hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);   // (always eight waves, whatever AG_MLP_THREADS is)
             return;
         }
         const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H3_WG_PER_CU));

@@ -278,7 +278,7 @@ def test_forward_repeatable_with_partial_last_tile(model):
 ])
 def test_weight_stationary_edge_encoder_is_bitwise_the_streaming_kernel(weights, material, n_obj, batch, kw):
     """Precision mode 2 runs its edge stack on the weight-stationary kernel by default (weights in registers, 32-edge blocks
-    pipelined through the four waves of one workgroup per CU, inline-asm MFMAs); ag_set_option("edge_stationary", 0) selects
+    pipelined through the eight waves of one workgroup per CU, inline-asm MFMAs); ag_set_option("edge_stationary", 0) selects
     the streaming kernel with the same two-product fp16 arithmetic.  Every row keeps its accumulation order, so the outputs
     must be bit-identical and repeatable — which also pins the hand-managed MFMA hazards and LDS hand-over of the new kernel."""
     m = make_model(weights, material, prec="fast")
