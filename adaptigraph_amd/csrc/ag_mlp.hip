@@ -1154,14 +1154,29 @@ __device__ __forceinline__ void ws_mfma(f32x16 &acc, const f16x8 &w, const bf16x
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
     }
 }
+// the two fp16 MFMAs of an input tile on one accumulator, back to back (the second takes the pipe's accumulate path), as ONE statement: hipcc pads
+// every asm statement whose outputs the next instruction reads with a wait state of its own
+template <bool ACC, bool FIRST>
+__device__ __forceinline__ void ws_mfma2(f32x16 &acc, const f16x8 &w0, const f16x8 &w1, const bf16x8 &x0, const bf16x8 &x1)
+{
+    if constexpr (FIRST) {
+        if constexpr (ACC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %3, 0\n\tv_mfma_f32_32x32x16_f16 %0, %2, %4, %0" : "=&v"(acc) : "a"(w0), "a"(w1), "v"(x0), "v"(x1));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %3, 0\n\tv_mfma_f32_32x32x16_f16 %0, %2, %4, %0" : "=&v"(acc) : "v"(w0), "v"(w1), "v"(x0), "v"(x1));
+    } else {
+        if constexpr (ACC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\tv_mfma_f32_32x32x16_f16 %0, %2, %4, %0" : "+v"(acc) : "a"(w0), "a"(w1), "v"(x0), "v"(x1));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\tv_mfma_f32_32x32x16_f16 %0, %2, %4, %0" : "+v"(acc) : "v"(w0), "v"(w1), "v"(x0), "v"(x1));
+    }
+}
 // acc += 2^(sa - 127) 2^(sb - 127) A8 . B8 over two 32-element K blocks: A e4m3 (cbsz 0), B e5m2 (blgp 1); the A scale is byte SEL of `sa` in the
 // lanes of the half with the block's number, the B scale byte 0 of `sb`
+// (the statement opens with the two wait states a VALU-written B operand needs before an MFMA reads it: the byte permutes that build it may be
+// scheduled anywhere above)
 template <bool ACC, int SEL>
 __device__ __forceinline__ void ws_mfma_mx(f32x16 &acc, const h3_i32x8 &a, const h3_i32x8 &b, unsigned sa, unsigned sb)
 {
 #define AG_MX(OPS) \
-    do { if constexpr (ACC) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "a"(a), "v"(b), "v"(sa), "v"(sb)); \
-         else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb)); } while (0)
+    do { if constexpr (ACC) asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "a"(a), "v"(b), "v"(sa), "v"(sb)); \
+         else asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS " cbsz:0 blgp:1" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb)); } while (0)
     if constexpr (SEL == 0) AG_MX("op_sel:[0,0,0] op_sel_hi:[0,0,0]");
     else if constexpr (SEL == 1) AG_MX("op_sel:[1,0,0] op_sel_hi:[0,0,0]");
     else if constexpr (SEL == 2) AG_MX("op_sel:[0,0,0] op_sel_hi:[1,0,0]");
@@ -1172,20 +1187,24 @@ __device__ __forceinline__ void ws_mfma_mx(f32x16 &acc, const h3_i32x8 &a, const
 // Epilogue of the hidden layers in eight pieces.  M = 0..7 of out-tile T: half S = M >> 2, output dword M & 3 (two accumulator values):
 // ReLU, packed fp16 convert, largest-pattern tracking, the two residual bytes (h3_pair); the fourth dword stores the consumer's 16 bytes
 // of k16-step 2T + S (bias column: feature 150 := 1.0) and its 8 residual bytes (residual image: [5 input tiles][64 lanes][16 bytes]).
-struct WsEpi { ws_u32x4 H; int R0, R1; unsigned bad; };
+struct WsEpi { ws_u32x4 H; int R[4]; unsigned bad; };
 typedef __attribute__((address_space(3))) unsigned char lds_u8;      // LDS pointers stay in their address space: a store is one ds_write with an
                                                                      // immediate offset (through a generic pointer: two address instructions each)
 template <int T, int M>
 __device__ __forceinline__ void ws_act_micro(const f32x16 &acc, WsEpi &E, lds_u8 *set_lane, int h)
 {
     constexpr int S = M >> 2, w = M & 3;
-    E.H[w] = h3_pair(relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1]), w < 2 ? E.R0 : E.R1, (w & 1) != 0, E.bad);
+    unsigned untracked = 0;
+    E.H[w] = h3_pair<false>(relu1(acc[8 * S + 2 * w]), relu1(acc[8 * S + 2 * w + 1]), E.R[2 * S + (w >> 1)], (w & 1) != 0, untracked);
+    // largest fp16 pattern so far (inf / NaN = an overflow of this layer): the values are >= 0, so the float maximum is the integer one; NaN propagates
+    if constexpr ((w & 1) == 1) asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(E.bad) : "v"(E.H[w - 1]), "v"(E.H[w]));
     if constexpr (w == 3) {
         if constexpr (T == 4 && S == 1) {           // feature 150 = 16*9 + 6: element e = 2 of the h = 1 half (its residual byte is 0: the feature is padding)
             if (h == 1) E.H[1] = (E.H[1] & 0xffff0000u) | 0x3c00u;
         }
         *reinterpret_cast<__attribute__((address_space(3))) ws_u32x4 *>(set_lane + (2 * T + S) * 1024) = E.H;
-        *reinterpret_cast<__attribute__((address_space(3))) ws_i32x2 *>(set_lane + AG_WS_IMG + T * 1024 + S * 8) = ws_i32x2{E.R0, E.R1};
+        if constexpr (S == 1)
+            *reinterpret_cast<__attribute__((address_space(3))) ws_u32x4 *>(set_lane + AG_WS_IMG + T * 1024) = ws_u32x4{(unsigned)E.R[0], (unsigned)E.R[1], (unsigned)E.R[2], (unsigned)E.R[3]};
     }
 }
 // We: one out-tile of the q16 table in seven chores (format and helpers: RowStoreQ16Epi above): 0, 1 the lane's maximum over its 16 values,
@@ -1307,13 +1326,9 @@ __device__ __forceinline__ void ws_phase(const WsUnit (&W)[NW], f32x16 (&acc)[NA
         ws_wait3<0>(xa, xb, r);
         h3_i32x8 &B = Bq[t & 1];
         B = h3_b_operand(h3_top_bytes(__builtin_bit_cast(h3_u32x4, xa), __builtin_bit_cast(h3_u32x4, xb)), __builtin_bit_cast(h3_u32x4, r));
-        asm volatile("s_nop 1" : "+v"(B));      // VALU write -> asm MFMA read: two wait states
-        // A dependent MFMA issued straight after its predecessor uses the pipe's accumulate path; with ONE other MFMA between them it waits for the
-        // predecessor's write-back (traced: 480 cycles per tile of two accumulators in the order a b a b a b, pipe time 256)
         static_for<0, NA>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            ws_mfma<(2 * (U0 + k) < NACC2), (t == 0)>(acc[U0 + k], W[U0 + k].hi[2 * t], xa);
-            ws_mfma<(2 * (U0 + k) < NACC2), false>(acc[U0 + k], W[U0 + k].hi[2 * t + 1], xb);
+            ws_mfma2<(2 * (U0 + k) < NACC2), (t == 0)>(acc[U0 + k], W[U0 + k].hi[2 * t], W[U0 + k].hi[2 * t + 1], xa, xb);
         });
         if constexpr (t + 1 < AG_NT) {
             lds_read16<(2 * t + 2) * 1024>(xa, la);
@@ -1366,7 +1381,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
         const size_t e = ((i >= 0 && i < n_i) ? (size_t)gblock(i) * 32 : e_pad) + j;
         return reinterpret_cast<unsigned char *>(a.eterm) + e * (2 * AG_FP);
     };
-    WsEpi Ep{{0u, 0u, 0u, 0u}, 0, 0, 0u};
+    WsEpi Ep{{0u, 0u, 0u, 0u}, {0, 0, 0, 0}, 0u};
     const uint32_t *wsc = w.edge_scale_h3;      // block scales of unit k (stream chunk 1 + k): wsc + 128 k
     auto load_unit = [&](WsUnit &U, int chunk) { ws_load_unit<true, true>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };
     auto load_unit2 = [&](WsUnit &U, int chunk) { ws_load_unit<true, false>(U, ws + (size_t)chunk * AG_CHUNK_F4, wsc + (size_t)(chunk - 1) * 128, lane); };

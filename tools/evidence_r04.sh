@@ -10,6 +10,7 @@ python tools/dyn_err.py > $EV/r04_dyn_err.txt 2>/dev/null
 python tools/stress_repeat.py 300 > $EV/r04_stress_repeat.txt 2>/dev/null
 ./tools/ubench/mx_lone > $EV/r04_mx_lone_ubench.txt 2>&1
 ./tools/ubench/cvt_formats > $EV/r04_cvt_formats.txt 2>&1
+./tools/ubench/valu_beside_mfma > $EV/r04_valu_beside_mfma.txt 2>&1
 if [ "$1" != "quick" ]; then
 {
 echo "# bench_mpc.py on one MI355X (precision fast): BASELINE configs[4] and the reference planner's shipped shape (config/planning/rope.yaml:28-42)"
