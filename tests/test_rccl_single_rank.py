@@ -118,3 +118,21 @@ def test_mpc_bench_two_ranks_one_gpu_over_gloo():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["config"]["parallelism"] == "samples/2"
+
+
+def test_mpc_bench_eight_ranks_one_gpu_over_gloo():
+    """The argument / JSON contract of `bench_mpc.py --gpus 8` (BASELINE configs[4] on a full node), with the eight ranks on the one leased
+    GPU and the collective over gloo: 60 samples do not divide by 8 (ranks get 8, 8, 8, 8, 7, 7, 7, 7), every rank must reach the
+    all-gather, rank 0 alone prints the line."""
+    import json
+    env = dict(os.environ, AG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 90), os.path.join(ROOT, "bench_mpc.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--particles", "100", "--samples", "60", "--push-steps", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0 and line["higher_is_better"] is False
+    assert line["config"]["parallelism"] == "samples/8" and line["config"]["samples"] == 60 and line["steps"] == 2 and line["warmup"] == 1
