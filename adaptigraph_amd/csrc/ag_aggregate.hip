@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 // adjacent lanes of one wave own a node, three nodes per wave, twelve per workgroup (240 of 256 lanes busy).
 constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 
+template <bool HSQ>
 __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 {
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     const int g = logical * kNodesPerBlockH + wave * AG_AGG_NODES_PER_WAVE + grp;
     if (g >= a.B * a.N) return;
     float4 acc0, acc1;
-    ag_reduce_node_q16(a, g, c, grp * AG_AGG_GROUP, acc0, acc1);
+    ag_reduce_node_q16<AG_AGG_IN_FLIGHT, HSQ>(a, g, c, grp * AG_AGG_GROUP, acc0, acc1);      // (6 or 8 edges in flight with the q16 sender table: no change)
     const int f0 = ag_half_lane_feature(c);
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0) = acc0;
     *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
@@ -90,7 +91,9 @@ void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s)
 {
     const int nodes = a.B * a.N;
     if (a.eterm_half) {
-        hipLaunchKernelGGL(aggregate_half_kernel, dim3((nodes + kNodesPerBlockH - 1) / kNodesPerBlockH), dim3(256), 0, s, a);
+        const dim3 grid((nodes + kNodesPerBlockH - 1) / kNodesPerBlockH);
+        if (a.hs_q16) hipLaunchKernelGGL(aggregate_half_kernel<true>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(aggregate_half_kernel<false>, grid, dim3(256), 0, s, a);
         return;
     }
     const int nb = (nodes + kNodesPerBlock - 1) / kNodesPerBlock;

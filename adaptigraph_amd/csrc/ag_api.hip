@@ -452,6 +452,8 @@ void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
                 r.h_rows = a.h0c;
             }
         }
+        r.hs_q16 = (a.eterm_half && p > 0) ? 1 : 0;                     // rounds after the first gather the q16 rows the previous node_update wrote
+        r.hs_out_q16 = (a.eterm_half && p + 1 < a.pstep) ? 1 : 0;
         if (!r.fuse_agg) { Timed t(m, AG_K_AGGREGATE, s); ag_launch_aggregate(r, s); }
         { Timed t(m, AG_K_NODE_UPDATE, s); ag_launch_node_update(m->w, r, p == a.pstep - 1, s); }
         std::swap(a.hr, a.hr_out);

@@ -70,6 +70,8 @@ struct AgFwdArgs {
     float clamp;
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
     float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
+    int hs_q16, hs_out_q16;   // precision mode 2: the sender table `hs` read / the one written by this launch holds q16 rows (320 B, the Eterm format) instead
+                              // of fp32 rows — the rounds after the first; round 0 gathers the node encoder's fp32 rows
     int precision;     // AG_PREC_F32 (exact fp32 MFMA) or AG_PREC_B3 (hi/lo bf16 split, 3 MFMAs per product)
     int eterm_half;    // 1: the Eterm table is 16-bit block-scaled fixed point in accumulator order (q16, precision mode 2)
     int fuse_agg;      // 1: node_update does the segment reduce itself (no aggregate launch, no agg table)
@@ -129,13 +131,18 @@ __device__ __forceinline__ float ag_q16_scale(int eb) { return ldexpf(1.0f / 327
 #define AG_AGG_NODES_PER_WAVE 3
 __device__ __forceinline__ int ag_half_lane_feature(int c) { return 32 * (c >> 2) + 8 * (2 * (c & 1)) + 4 * ((c >> 1) & 1); }
 
-template <int kInFlight = AG_AGG_IN_FLIGHT>
+// HSQ: the sender table is q16 too (rows of the Eterm format written by node_update's RowStoreQ16Epi): ONE 16-byte load per edge and lane instead of
+// two, half the gathered bytes.  Sender terms are independent per edge, so their 16-bit rounding averages out over a receiver's edges (float64
+// emulation on the random sweep's cases: worst deviation 8.3e-6 -> 8.5e-6); the receiver term Hr, common to all edges of a node, stays fp32
+// (as q16 it adds coherently: 1.5e-5).
+template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
 __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
 {
     const int f0 = ag_half_lane_feature(c);
     const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
     const int4 *et = reinterpret_cast<const int4 *>(a.eterm) + c;          // segment c of row e: et[e * 20]
     const float *hs = a.hs + f0;
+    const int4 *hq = reinterpret_cast<const int4 *>(a.hs) + c;             // HSQ: segment c of sender row s: hq[s * 20]
     const int exp_src = (group_lane0 + (c < 16 ? 17 : 19)) << 2;           // ds_bpermute byte address of the lane that loaded the exponent bytes
     const int exp_shift = c < 16 ? 8 * (c >> 2) : 0;
     int s[kInFlight];
@@ -150,14 +157,17 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
         int sn[kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) sn[i] = e + kInFlight + i < e1 ? a.edge_send[e + kInFlight + i] : -1;
-        int4 t[kInFlight];
-        float4 u0[kInFlight], u1[kInFlight];
+        int4 t[kInFlight], v[HSQ ? kInFlight : 1];
+        float4 u0[HSQ ? 1 : kInFlight], u1[HSQ ? 1 : kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
                 t[i] = et[(size_t)(e + i) * (AG_FP / 8)];
-                u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
-                u1[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP + 8);
+                if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
+                else {
+                    u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
+                    u1[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP + 8);
+                }
             }
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
@@ -166,10 +176,21 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
                 const float sc = ag_q16_scale(eb);
                 const float q0 = (float)(short)(t[i].x & 0xffff), q1 = (float)(t[i].x >> 16), q2 = (float)(short)(t[i].y & 0xffff), q3 = (float)(t[i].y >> 16);
                 const float q4 = (float)(short)(t[i].z & 0xffff), q5 = (float)(t[i].z >> 16), q6 = (float)(short)(t[i].w & 0xffff), q7 = (float)(t[i].w >> 16);
-                acc0.x += fmaxf(fmaf(q0, sc, hr0.x) + u0[i].x, 0.f); acc0.y += fmaxf(fmaf(q1, sc, hr0.y) + u0[i].y, 0.f);
-                acc0.z += fmaxf(fmaf(q2, sc, hr0.z) + u0[i].z, 0.f); acc0.w += fmaxf(fmaf(q3, sc, hr0.w) + u0[i].w, 0.f);
-                acc1.x += fmaxf(fmaf(q4, sc, hr1.x) + u1[i].x, 0.f); acc1.y += fmaxf(fmaf(q5, sc, hr1.y) + u1[i].y, 0.f);
-                acc1.z += fmaxf(fmaf(q6, sc, hr1.z) + u1[i].z, 0.f); acc1.w += fmaxf(fmaf(q7, sc, hr1.w) + u1[i].w, 0.f);
+                if constexpr (HSQ) {
+                    const int ebs = (__builtin_amdgcn_ds_bpermute(exp_src, v[i].z) >> exp_shift) & 0xff;
+                    const float ss = ag_q16_scale(ebs);
+                    const float p0 = (float)(short)(v[i].x & 0xffff), p1 = (float)(v[i].x >> 16), p2 = (float)(short)(v[i].y & 0xffff), p3 = (float)(v[i].y >> 16);
+                    const float p4 = (float)(short)(v[i].z & 0xffff), p5 = (float)(v[i].z >> 16), p6 = (float)(short)(v[i].w & 0xffff), p7 = (float)(v[i].w >> 16);
+                    acc0.x += fmaxf(fmaf(p0, ss, fmaf(q0, sc, hr0.x)), 0.f); acc0.y += fmaxf(fmaf(p1, ss, fmaf(q1, sc, hr0.y)), 0.f);
+                    acc0.z += fmaxf(fmaf(p2, ss, fmaf(q2, sc, hr0.z)), 0.f); acc0.w += fmaxf(fmaf(p3, ss, fmaf(q3, sc, hr0.w)), 0.f);
+                    acc1.x += fmaxf(fmaf(p4, ss, fmaf(q4, sc, hr1.x)), 0.f); acc1.y += fmaxf(fmaf(p5, ss, fmaf(q5, sc, hr1.y)), 0.f);
+                    acc1.z += fmaxf(fmaf(p6, ss, fmaf(q6, sc, hr1.z)), 0.f); acc1.w += fmaxf(fmaf(p7, ss, fmaf(q7, sc, hr1.w)), 0.f);
+                } else {
+                    acc0.x += fmaxf(fmaf(q0, sc, hr0.x) + u0[i].x, 0.f); acc0.y += fmaxf(fmaf(q1, sc, hr0.y) + u0[i].y, 0.f);
+                    acc0.z += fmaxf(fmaf(q2, sc, hr0.z) + u0[i].z, 0.f); acc0.w += fmaxf(fmaf(q3, sc, hr0.w) + u0[i].w, 0.f);
+                    acc1.x += fmaxf(fmaf(q4, sc, hr1.x) + u1[i].x, 0.f); acc1.y += fmaxf(fmaf(q5, sc, hr1.y) + u1[i].y, 0.f);
+                    acc1.z += fmaxf(fmaf(q6, sc, hr1.z) + u1[i].z, 0.f); acc1.w += fmaxf(fmaf(q7, sc, hr1.w) + u1[i].w, 0.f);
+                }
             }
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i) s[i] = sn[i];

@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 // graph-steps/s), so this is ag_set_option("fuse_aggregate", 2), not the default.  Keeping 8 edges or three nodes per lane in
 // flight changed nothing (0.473 / 0.475 ms): the round is bandwidth-bound at what this access mix reaches, not latency-bound.
 #define AG_STAGE_LD 164
-template <class Prec, bool LAST, bool FUSE>
+template <class Prec, bool LAST, bool FUSE, bool HSQ = false>      // HSQ: the next round's sender table is written as q16 rows (mode 2)
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
@@ -1602,7 +1602,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                     if (ng < AG_AGG_NODES_PER_WAVE && r < 32) {
                         const int gn = tile * AG_ROWS_PER_BLOCK + grp * 32 + r;
                         float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-                        if (gn < Mn) ag_reduce_node_q16(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                        if (gn < Mn) {
+                            if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true>(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                            else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false>(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                        }
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;
                     }
@@ -1639,7 +1642,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff});
-            dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff});
+            if constexpr (HSQ) dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreQ16Epi{reinterpret_cast<unsigned char *>(a.hs_out) + (size_t)g * (2 * AG_FP), h, a.status});
+            else dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hs_out + rowoff});
         } else {
             dense<Prec, AG_F, true, false>(P, x, y, resid);   // particle_effect'
             q.publish();
@@ -1915,8 +1919,10 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
     if (a.precision == AG_PREC_B3) {
         if (a.fuse_agg == 2 && a.eterm_half) {      // cooperative LDS-staged reduce inside the kernel (no aggregate launch, no agg table)
             if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, true>), grid, block, 0, s, w, a);
+            else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true, true>), grid, block, 0, s, w, a);
             else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true>), grid, block, 0, s, w, a);
         } else if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false>), grid, block, 0, s, w, a);
+        else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true>), grid, block, 0, s, w, a);
         else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false>), grid, block, 0, s, w, a);
     } else {
         if (last) hipLaunchKernelGGL((node_update_kernel<PrecF32, true, false>), grid, block, 0, s, w, a);

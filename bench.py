@@ -290,8 +290,10 @@ class Engine:
                 # HBM once per node, then L2), Hr read + agg written per node (SURVEY §8d B_alg terms)
                 n_nodes = batch * (WORKLOADS[self.material]["n_obj"] + synth.MATERIALS[self.material]["n_tools"])
                 # node tables per launch: Hr read + Hs first-touch + agg write = 3 x 640 B per node; with the node encoder de-duplicated
-                # (default) round 0 reads Hr / Hs from a few compact rows, so the three rounds average (1 + 3 + 3) / 3 tables
-                tables = 3.0 if os.environ.get("AG_NODE_DEDUP", "1") == "0" else 7.0 / 3.0
+                # (default) round 0 reads Hr / Hs from a few compact rows, so the three rounds average (1 + 3 + 3) / 3 tables.  In the default
+                # mode the rounds after the first gather Hs from q16 rows (320 B per node): 2.5 tables there
+                later = 2.5 if precision == "fast" else 3.0
+                tables = (3.0 + 2 * later) / 3.0 if os.environ.get("AG_NODE_DEDUP", "1") == "0" else (1.0 + 2 * later) / 3.0
                 nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * tables * 640
                 a_s = ms[ka] / cnt[ka] * 1e-3
                 t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
