@@ -416,7 +416,8 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
               (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
     a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
-        // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2: 128 -> 113.3 k, 192 -> 115.4 k, 256 -> 114.2 k)
+        // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2, r04: 128 CUs -> 127.8 k, 160 -> 133.3 k, 192 -> 134.2 k, 224 -> 132.1 k,
+        // 256 -> 132.0 k graph-steps/s)
         const int full = m->max_blocks / AG_MLP_WG_PER_CU, share = max_blocks / AG_MLP_WG_PER_CU * 3 / 2;
         a.ws_blocks = share < full ? (share > 0 ? share : 1) : (full > 0 ? full : 1);
     }
