@@ -238,7 +238,7 @@ struct ag_model {
     int edge_products = 2;      // precision mode 2: 2 = fp16 edge stack (split-fp16 weights x fp16 activations + e5m2 residual bytes: PrecH3),
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
-    int edge_ws = 1;            // two-product edge stack on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
+    int edge_ws = 1;            // fp16 edge stack (PrecH3) on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
                                 // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
@@ -304,7 +304,7 @@ int pack_and_upload(ag_model *m, const float *const *t)
         AG_HIP(hipDeviceSynchronize());
     }
     AG_HIP(hipMemcpy(m->dev, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
-    // two-product fp16 edge stack (precision mode 2): only if every edge-stack weight and bias is representable in fp16
+    // fp16 edge stack (precision mode 2, PrecH3): only if every edge-stack weight and bias is representable in fp16
     {
         bool ok = true;
         auto fits = [&](const float *p, size_t n, size_t ld = 0, size_t cols = 0) {
