@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void edge_features(const AgFwdArgs &a, const EdgeRaw 
 //    instructions take ~10 cycles each (packed fp32 VALU 39: none are used here).  So a wave runs its 30 MFMAs, then its epilogues as plain
 //    code, and the two waves of a SIMD are kept in OPPOSITE halves of their rounds: waves 2-5 start a round with the epilogue of the
 //    accumulators they computed in the previous round, their partners start with their MFMAs.  Until r04 the kernel ran four waves of 512
-//    registers with every epilogue cut into micro-chores pinned into MFMA shadows: 0.72 ms against 0.675 for this one.
+//    registers with every epilogue cut into micro-chores pinned into MFMA shadows: 0.72 ms against 0.61 for this one.
 //  * A dependent MFMA issued straight after its predecessor uses the pipe's accumulate path; results of asm MFMAs are not interlocked against
 //    compiler-placed readers (ws_settle), a VALU-written B operand needs two wait states (s_nop 1), and the scaled MFMA reads its eight B
 //    registers over several passes after issue (two register sets by tile parity).
