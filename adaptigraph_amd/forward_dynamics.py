@@ -22,17 +22,20 @@ def _u8(t):
 
 def rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr_sq, repeat, n_steps, topk,
             connect_tools_all, max_tools, height_mode=_lib.AG_HEIGHT_MIN, obj_mask=None, gripper_raise=0.0,
-            return_state=False):
+            return_state=False, out=None):
     """Native inner loop (forward_dynamics.py:156-197).  All tensors on the model's GPU.
     state0 (B,H,N,3), delta (B,N,3), attrs (B,N,2), p_instance (B,n_p,I), phys (B,P), mask/tool_mask (B,N) bool,
-    thr_sq (B,), repeat (B,) int32 -> out_seq (B,n_p,3): prediction of step repeat[b] (zeros if never reached)."""
+    thr_sq (B,), repeat (B,) int32 -> out_seq (B,n_p,3): prediction of step repeat[b] (zeros if never reached).
+    `out`: an already ZEROED contiguous fp32 (B,n_p,3) tensor to write into instead of a fresh one."""
     L = _lib.lib()
     dev = state0.device
     B, H, N, _ = state0.shape
     n_p, n_inst = p_instance.shape[1], p_instance.shape[2]
     prm = _lib.RolloutParams(B, N, n_p, n_inst, int(topk), 1 if connect_tools_all else 0, int(max_tools), int(n_steps),
                              int(height_mode), float(gripper_raise))
-    out_seq = torch.zeros((B, n_p, 3), dtype=torch.float32, device=dev)
+    if out is not None:
+        assert out.shape == (B, n_p, 3) and out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
+    out_seq = out if out is not None else torch.zeros((B, n_p, 3), dtype=torch.float32, device=dev)
     state_final = torch.empty_like(state0, dtype=torch.float32) if return_state else None
     ws = workspace(dev, L.ag_rollout_workspace_bytes(ctypes.byref(prm)))
     state0 = state0.contiguous().float()
@@ -96,6 +99,30 @@ def _physics(ppm_optimizer, physics_param, bsz, device):
     return p[None].repeat(bsz, 1)
 
 
+_CONST = {}      # per (batch, particles, tools, instances, device): the call-invariant inputs of dynamics()
+
+
+def _constants(bsz, n_obj, n_t, max_n, device):
+    """attrs / p_instance / mask / tool_mask of forward_dynamics.py:83-123 depend only on the shapes: built once, read-only afterwards
+    (a dozen tiny launches per call otherwise, issued while the GPU idles behind the call's one host sync)."""
+    key = (bsz, n_obj, n_t, max_n, str(device))
+    c = _CONST.get(key)
+    if c is None:
+        N = n_obj + n_t
+        attrs = torch.zeros((bsz, N, 2), device=device)
+        attrs[:, :n_obj, 0] = 1.0
+        attrs[:, n_obj:, 1] = 1.0
+        p_instance = torch.zeros((bsz, n_obj, max_n), device=device)
+        p_instance[:, :, 0] = 1.0
+        mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
+        tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
+        tool_mask[:, n_obj:] = True
+        if len(_CONST) >= 16:
+            _CONST.clear()
+        c = _CONST[key] = (attrs, p_instance, mask, tool_mask)
+    return c
+
+
 @torch.no_grad()
 def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     task = ppm_optimizer.task_config
@@ -107,24 +134,14 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     n_obj, n_t = state.shape[0], ppm_optimizer.eef_num
     N = n_obj + n_t
 
-    attrs = torch.zeros((bsz, N, 2), device=device)
-    attrs[:, :n_obj, 0] = 1.0
-    attrs[:, n_obj:, 1] = 1.0
-    p_instance = torch.zeros((bsz, n_obj, task["max_n"]), device=device)
-    p_instance[:, :, 0] = 1.0
-    mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
-    tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
-    tool_mask[:, n_obj:] = True
+    attrs, p_instance, mask, tool_mask = _constants(bsz, n_obj, n_t, task["max_n"], device)
     phys = _physics(ppm_optimizer, physics_param, bsz, device)
     thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
-    max_steps = repeat.max(dim=0).values.tolist()     # ONE host sync per call (reference: one per look-ahead + 3 per step)
-    model.take_status(device)                         # deferred numeric status of the previous calls (rides on that sync)
-
+    rep_max = repeat.max(dim=0).values
+    rep_cols = repeat.to(torch.int32).t().contiguous()      # (n_look, B): each look-ahead step's column contiguous, made before the sync
     seq = torch.zeros((bsz, n_look, n_obj, 3), device=device)
-    obj = state[None].expand(bsz, n_obj, 3)
-    for li in range(n_look):
-        if li > 0:
-            obj = seq[:, li - 1]
+
+    def prepare(li, obj):        # tool key-points, history frames and per-step tool motion of look-ahead step li
         y = obj[:, :, 1].min(dim=1).values
         eef, dlt, raise_by = _place_tool(task, decoded[:, li], action[:, li, 2], y, device)
         state0 = torch.empty((bsz, n_his, N, 3), device=device)
@@ -132,9 +149,23 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
         state0[:, :, n_obj:] = eef[:, None]
         delta = torch.zeros((bsz, N, 3), device=device)
         delta[:, n_obj:] = dlt
-        seq[:, li] = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, repeat[:, li],
-                             max_steps[li], task["topk"], task["connect_tools_all"], n_t,
-                             _lib.AG_HEIGHT_MIN, None, raise_by)
+        return state0, delta, raise_by
+
+    # everything the first look-ahead step needs is enqueued BEFORE the call's one host sync, so that after it only the rollout's own launches
+    # stand between the host and a busy GPU
+    ready = prepare(0, state[None].expand(bsz, n_obj, 3))
+    max_steps = rep_max.tolist()                      # ONE host sync per call (reference: one per look-ahead + 3 per step)
+    model.take_status(device)                         # deferred numeric status of the previous calls (rides on that sync)
+    for li in range(n_look):
+        if li > 0:
+            ready = prepare(li, seq[:, li - 1])
+        state0, delta, raise_by = ready
+        direct = seq[:, 0] if n_look == 1 else None     # a single look-ahead step: the library writes the result tensor itself
+        res = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, rep_cols[li],
+                      max_steps[li], task["topk"], task["connect_tools_all"], n_t,
+                      _lib.AG_HEIGHT_MIN, None, raise_by, out=direct)
+        if direct is None:
+            seq[:, li] = res
     return {"state_seqs": seq, "action_seqs": decoded}
 
 
