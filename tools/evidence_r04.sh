@@ -33,4 +33,7 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 python $REPO/tools/rocpd_summary.py pmc $(find $EV/pmc_sq -name "*.db" | head -1) > $EV/r04_edge_pmc.txt 2>/dev/null
 rm -rf $EV/pmc_sq
 timeout 1500 python $REPO/tools/pmc_traffic.py --out $EV/pmc_traffic.json > /dev/null 2>&1
+# the bench line once more, now that the traffic file matches the sources being run (bench.py quotes it only then)
+cp $EV/pmc_traffic.json $REPO/profiles/pmc_traffic.json
+cd $REPO && python bench.py --steps 20 --warmup 5 > $EV/r04_bench.json 2>> $EV/bench.err
 ls -la $EV
