@@ -246,6 +246,14 @@ struct ag_model {
     int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // CU partitioning of the rollout (env AG_CU_SPLIT / "cu_split"): the first `cu_split` CU-mask bits — cu_split / 8 CUs of EVERY
+    // XCD (tools/ubench/cu_mask_map.hip: bit b = CU slot b / 8 of XCD b % 8) — run the MFMA-bound edge encoder, the other CUs the HBM-bound
+    // edge build / segment reduce / node update / state step, the batch parts pipelined through the two partitions.  0 = off.
+    int cu_split = 0;
+    int n_cus = 256;
+    int part_cus = 0;           // cu_split the two masked streams below were created for
+    hipStream_t mfma_stream = nullptr, hbm_stream = nullptr;
+    hipEvent_t ev_ready[4] = {nullptr, nullptr, nullptr, nullptr}, ev_enc[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join_mfma = nullptr;
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[AG_K_COUNT];
     size_t ev_used[AG_K_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -507,8 +515,11 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
             m->max_blocks = AG_MLP_WG_PER_CU * prop.multiProcessorCount;
+            m->n_cus = prop.multiProcessorCount;
+        }
+        if (const char *v = getenv("AG_CU_SPLIT")) m->cu_split = atoi(v);
         if (const char *v = getenv("AG_MAX_BLOCKS")) m->max_blocks = atoi(v);
     }
     int rc = pack_and_upload(m, weights);
@@ -542,6 +553,13 @@ int ag_model_destroy(ag_model *m)
         if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->mfma_stream) (void)hipStreamDestroy(m->mfma_stream);
+    if (m->hbm_stream) (void)hipStreamDestroy(m->hbm_stream);
+    for (int k = 0; k < 4; ++k) {
+        if (m->ev_ready[k]) (void)hipEventDestroy(m->ev_ready[k]);
+        if (m->ev_enc[k]) (void)hipEventDestroy(m->ev_enc[k]);
+    }
+    if (m->ev_join_mfma) (void)hipEventDestroy(m->ev_join_mfma);
     if (m->status) (void)hipFree(m->status);
     if (m->dev) (void)hipFree(m->dev);
     delete m;
@@ -741,6 +759,11 @@ int ag_set_option(ag_model *m, const char *name, int value)
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "cu_split")) {
+        if (value != 0 && (value < 8 || value > m->n_cus - 8 || (value & 7)))
+            return fail(AG_ERR_ARG, "ag_set_option: cu_split takes 0 (off) or a multiple of 8 in [8, %d], not %d", m->n_cus - 8, value);
+        m->cu_split = value;
+    }
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
     return AG_OK;
 }
@@ -899,6 +922,28 @@ static void part_range(int B, int parts, int k, int *b0, int *nb)
     *nb = (*b0 + per <= B) ? per : B - *b0;
 }
 
+// The two CU-masked streams of the partitioned rollout (created once per cu_split value).  Mask bit b is CU slot b / 8 of XCD b % 8
+// (tools/ubench/cu_mask_map.hip -> profiles/r05_cu_mask_map.txt), so bits [0, X) and [X, n_cus) with X a multiple of 8 are disjoint sets of
+// X / 8 and (n_cus - X) / 8 CUs of EVERY XCD: both partitions keep all eight L2s and all memory channels.
+static int ensure_partition(ag_model *m)
+{
+    if (m->mfma_stream && m->hbm_stream && m->part_cus == m->cu_split) return AG_OK;
+    if (m->mfma_stream) { (void)hipStreamSynchronize(m->mfma_stream); (void)hipStreamDestroy(m->mfma_stream); m->mfma_stream = nullptr; }
+    if (m->hbm_stream) { (void)hipStreamSynchronize(m->hbm_stream); (void)hipStreamDestroy(m->hbm_stream); m->hbm_stream = nullptr; }
+    const int words = (m->n_cus + 31) / 32;
+    std::vector<uint32_t> lo(words, 0u), hi(words, 0u);
+    for (int b = 0; b < m->n_cus; ++b) (b < m->cu_split ? lo : hi)[b >> 5] |= 1u << (b & 31);
+    AG_HIP(hipExtStreamCreateWithCUMask(&m->mfma_stream, (uint32_t)words, lo.data()));
+    AG_HIP(hipExtStreamCreateWithCUMask(&m->hbm_stream, (uint32_t)words, hi.data()));
+    for (int k = 0; k < 4; ++k) {
+        if (!m->ev_ready[k]) AG_HIP(hipEventCreateWithFlags(&m->ev_ready[k], hipEventDisableTiming));
+        if (!m->ev_enc[k]) AG_HIP(hipEventCreateWithFlags(&m->ev_enc[k], hipEventDisableTiming));
+    }
+    if (!m->ev_join_mfma) AG_HIP(hipEventCreateWithFlags(&m->ev_join_mfma, hipEventDisableTiming));
+    m->part_cus = m->cu_split;
+    return AG_OK;
+}
+
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
 {
     if (!p) return 0;
@@ -955,12 +1000,23 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
     }
     const size_t plane = (size_t)N * 3;
     const int part_blocks = m->max_blocks / parts > 0 ? m->max_blocks / parts : 1;   // each part's persistent kernels take an equal share
+    // CU-partitioned pipeline (cu_split > 0; needs >= 2 batch parts and the weight-stationary edge encoder, whose grid is one workgroup per CU)
+    const bool partitioned = m->cu_split >= 8 && m->cu_split <= m->n_cus - 8 && parts >= 2 && m->precision == AG_PREC_B3 && m->eterm_half &&
+                             m->edge_products == 2 && m->h2_ok && m->edge_ws && p->n_instance <= 1 && (long long)p->B * N * 4 < 0x7fffffffLL;
+    hipStream_t sE = nullptr, sR = nullptr;
+    if (partitioned) {
+        const int prc = ensure_partition(m);
+        if (prc != AG_OK) return prc;
+        sE = m->mfma_stream; sR = m->hbm_stream;
+        AG_HIP(hipStreamWaitEvent(sE, m->ev_fork, 0));
+        AG_HIP(hipStreamWaitEvent(sR, m->ev_fork, 0));
+    }
     int rc = AG_OK;
     // issue the steps round-robin over the parts so every stream always has work queued
     struct Run { AgStepArgs st{}; hipStream_t s; } run[AG_MAX_PARTS];
     for (int k = 0; k < parts && rc == AG_OK; ++k) {
         Part &q = part[k];
-        hipStream_t s = k == 0 ? s0 : m->aux_stream[k];
+        hipStream_t s = partitioned ? sR : (k == 0 ? s0 : m->aux_stream[k]);
         run[k].s = s;
         const size_t b0 = (size_t)q.b0;
         const size_t state_bytes = (size_t)q.B * H * plane * sizeof(float);
@@ -983,6 +1039,42 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         st.out_seq = out_seq + b0 * n_p * 3; st.B = q.B; st.N = N; st.n_p = n_p; st.H = H;
         st.height_mode = p->height_mode; st.raise = p->gripper_raise;
     }
+    if (partitioned) {
+        // Two in-order queues with disjoint CU masks.  HBM queue (sR): edge build -> [ready] ... [encoded] -> three propagation rounds -> state step;
+        // MFMA queue (sE): [ready] -> per-node input rows + edge encoder + sender remap -> [encoded].  Part k's step ai + 1 cannot start before its
+        // step ai has finished (the edges are rebuilt from the predicted positions), so with two parts the steady state is
+        //     sE:  E(A, i+1)  E(B, i+1)  E(A, i+2) ...          sR:  R(B, i)  R(A, i+1)  R(B, i+1) ...
+        // each partition always busy with its own kind of work, the other part's.  Every table is per part, and E(k, i+1) is ordered behind
+        // R(k, i) through `ready`, so nothing is overwritten while it is read.
+        // Enqueue order matters (both queues are in order): a part's NEXT edge build follows its own state step directly, and the wait for the
+        // encoder stands in front of the rounds that need it — not in front of the other part's edge build.
+        auto encode = [&](int k) {       // sR: [edges built] -> ready;  sE: ready -> encoder -> encoded
+            if (hipEventRecord(m->ev_ready[k], sR) != hipSuccess || hipStreamWaitEvent(sE, m->ev_ready[k], 0) != hipSuccess) return AG_ERR_HIP;
+            run_edge_encode(m, part[k].f, sE);
+            return hipEventRecord(m->ev_enc[k], sE) == hipSuccess ? AG_OK : AG_ERR_HIP;
+        };
+        for (int k = 0; k < parts && rc == AG_OK && p->n_steps > 0; ++k) {
+            AgFwdArgs &f = part[k].f;
+            { Timed tm(m, AG_K_EDGES, sR); ag_launch_build_edges(part[k].e, sR); }
+            setup_args(m, f, AG_MLP_WG_PER_CU * (m->n_cus - m->cu_split), p->n_steps);     // persistent node kernels: the HBM partition's CUs
+            f.ws_blocks = m->cu_split;                                                     // edge encoder: one workgroup per CU of the MFMA partition
+            run_node_encode(m, f, sR);
+            rc = encode(k);
+        }
+        for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
+            for (int k = 0; k < parts && rc == AG_OK; ++k) {
+                AgFwdArgs &f = part[k].f;
+                if (hipStreamWaitEvent(sR, m->ev_enc[k], 0) != hipSuccess) { rc = AG_ERR_HIP; break; }
+                run_propagate(m, f, sR);
+                run[k].st.step = ai;
+                { Timed tm(m, AG_K_ROLLOUT_STEP, sR); ag_launch_rollout_step(run[k].st, sR); }
+                if (ai < p->n_steps) {
+                    { Timed tm(m, AG_K_EDGES, sR); ag_launch_build_edges(part[k].e, sR); }
+                    if (!f.dedup) run_node_encode(m, f, sR);
+                    rc = encode(k);
+                }
+            }
+    } else
     for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
         for (int k = 0; k < parts && rc == AG_OK; ++k) {
             hipStream_t s = run[k].s;
@@ -1009,6 +1101,11 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
             rc = AG_ERR_HIP;
     }
     // every exit path joins the auxiliary streams back into the caller's stream
+    if (partitioned) {
+        if (hipEventRecord(m->ev_join_mfma, sE) != hipSuccess || hipStreamWaitEvent(s0, m->ev_join_mfma, 0) != hipSuccess ||
+            hipEventRecord(m->ev_join[1], sR) != hipSuccess || hipStreamWaitEvent(s0, m->ev_join[1], 0) != hipSuccess)
+            rc = AG_ERR_HIP;
+    } else
     for (int k = 1; k < parts; ++k)
         if (hipEventRecord(m->ev_join[k], m->aux_stream[k]) != hipSuccess || hipStreamWaitEvent(s0, m->ev_join[k], 0) != hipSuccess)
             rc = AG_ERR_HIP;

@@ -60,7 +60,7 @@ def assert_replicated(t, what="tensor", group=None):
                            "inputs (use dist.replicate() or seed every rank identically)")
 
 
-def gather_sharded(local, total, per, group=None, copy=True):
+def gather_sharded(local, total, per, group=None, copy=True, tag=""):
     """All-gather per-rank shards (<= per rows each) into the full (total, ...) tensor.
 
     Shards are contiguous and balanced (shard_bounds), so every rank before the last non-empty one is full and the
@@ -70,7 +70,7 @@ def gather_sharded(local, total, per, group=None, copy=True):
     until the next gather of the same shape)."""
     world = dist.get_world_size(group)
     tail = tuple(local.shape[1:])
-    out = _buffer("recv", (world * per,) + tail, local.dtype, local.device)
+    out = _buffer("recv" + tag, (world * per,) + tail, local.dtype, local.device)
     if local.shape[0] == per and local.is_contiguous():
         send = local
     else:
@@ -81,9 +81,13 @@ def gather_sharded(local, total, per, group=None, copy=True):
     return res.clone() if copy else res
 
 
-def dynamics_sharded(dynamics_fn, state, action, *args, group=None, timing=None, **kwargs):
+def dynamics_sharded(dynamics_fn, state, action, *args, group=None, timing=None, copy=True, **kwargs):
     """Run `dynamics_fn(state, action_shard, *args)` on this rank's slice of the (replicated) action samples and
     all-gather `state_seqs` / `action_seqs` so every rank returns the full-batch result.
+
+    `copy=False`: the returned tensors are views of the cached receive buffers (no extra device copy of the gathered states:
+    12 MB per call at BASELINE configs[4]); they stay valid until the next call with the same shapes — what a planner that scores
+    the states right away (mpc.py, bench.py) wants.
 
     `timing`, if given, is a dict of lists: a (start, end) pair of CUDA events is appended under "rollout" and
     "gather" for the local rollout and the collective of this call (resolve with `elapsed_ms` after a sync)."""
@@ -102,7 +106,7 @@ def dynamics_sharded(dynamics_fn, state, action, *args, group=None, timing=None,
                "action_seqs": torch.zeros((0, action.shape[1], 4), device=action.device)}
     if ev:
         ev[1].record()
-    res = {k: gather_sharded(v, total, per, group) for k, v in out.items()}
+    res = {k: gather_sharded(v, total, per, group, copy=copy, tag=":" + k) for k, v in out.items()}
     if ev:
         ev[2].record()
         timing.setdefault("rollout", []).append((ev[0], ev[1]))

@@ -7,7 +7,9 @@ action) is a handful of tiny device tensor ops; the inner loop — edges -> GNN 
 tool advance -> history shift -> edge rebuild — is one `ag_rollout` call with no host synchronisation
 (the reference syncs three times per step: truncate_graph, n_rels.max().item(), pad_torch).
 """
+import collections
 import ctypes
+import os
 
 import torch
 
@@ -99,35 +101,59 @@ def _physics(ppm_optimizer, physics_param, bsz, device):
     return p[None].repeat(bsz, 1)
 
 
-_CONST = {}      # per (batch, particles, tools, instances, device): the call-invariant inputs of dynamics()
+_CONST = collections.OrderedDict()      # per (batch, particles, tools, instances, device): the call-invariant inputs of dynamics(), LRU of _CONST_MAX
+_CONST_MAX = 4                          # entries (an MPPI loop alternates between its chunk size and the bsz = 1 best-sample rollout: 2 live keys)
+_CONST_MAX_BYTES = 256 << 20            # and device bytes (20 000 samples x 200 particles: 66 MB per entry)
 _PINNED = {}
 
 
-def _pinned(n, dtype):
-    t = _PINNED.get((n, dtype))
+def _pinned(n, dtype, device):
+    """One pinned host buffer per (length, dtype, device): streams of different devices never share a staging buffer."""
+    key = (n, dtype, str(device))
+    t = _PINNED.get(key)
     if t is None:
-        t = _PINNED[(n, dtype)] = torch.empty(n, dtype=dtype, pin_memory=True)
+        t = _PINNED[key] = torch.empty(n, dtype=dtype, pin_memory=True)
     return t
 
 
+def _strict_status(model, device):
+    """AG_STRICT_STATUS=1: read the model's numeric status at the END of the call that may have raised it (one more host round trip per call)
+    and raise instead of warning; by default the status of call k is seen by call k + 1's read (sync-free), or by an explicit
+    model.take_status()."""
+    if os.environ.get("AG_STRICT_STATUS", "0") == "1":
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            flags = model.take_status(device)
+        if flags:
+            raise FloatingPointError(f"adaptigraph_amd: this rollout left the range of its arithmetic (ag_model_status = {flags}): non-finite "
+                                     "inputs, or an fp16 activation of the 'fast' edge stack beyond 65504 — use model.set_option('precision', 1)")
+
+
 def _constants(bsz, n_obj, n_t, max_n, device):
-    """attrs / p_instance / mask / tool_mask of forward_dynamics.py:83-123 depend only on the shapes: built once, read-only afterwards
-    (a dozen tiny launches per call otherwise, issued while the GPU idles behind the call's one host sync)."""
+    """attrs / p_instance / mask / tool_mask of forward_dynamics.py:83-123 depend only on the shapes: built once per shape (a dozen tiny
+    launches per call otherwise, issued while the GPU idles behind the call's one host sync).  A small LRU bounded by entries AND bytes, so
+    varying MPPI chunk sizes (20 000 samples, chunks, the bsz = 1 best-sample rollout) cannot pile up device memory.
+    READ-ONLY: the tensors are shared by every later call with the same shapes — callers must not write into them."""
     key = (bsz, n_obj, n_t, max_n, str(device))
     c = _CONST.get(key)
-    if c is None:
-        N = n_obj + n_t
-        attrs = torch.zeros((bsz, N, 2), device=device)
-        attrs[:, :n_obj, 0] = 1.0
-        attrs[:, n_obj:, 1] = 1.0
-        p_instance = torch.zeros((bsz, n_obj, max_n), device=device)
-        p_instance[:, :, 0] = 1.0
-        mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
-        tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
-        tool_mask[:, n_obj:] = True
-        if len(_CONST) >= 16:
-            _CONST.clear()
-        c = _CONST[key] = (attrs, p_instance, mask, tool_mask)
+    if c is not None:
+        _CONST.move_to_end(key)
+        return c
+    N = n_obj + n_t
+    attrs = torch.zeros((bsz, N, 2), device=device)
+    attrs[:, :n_obj, 0] = 1.0
+    attrs[:, n_obj:, 1] = 1.0
+    p_instance = torch.zeros((bsz, n_obj, max_n), device=device)
+    p_instance[:, :, 0] = 1.0
+    mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
+    tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
+    tool_mask[:, n_obj:] = True
+    c = (attrs, p_instance, mask, tool_mask)
+    nbytes = lambda e: sum(t.numel() * t.element_size() for t in e)      # noqa: E731
+    while _CONST and (len(_CONST) >= _CONST_MAX or sum(map(nbytes, _CONST.values())) + nbytes(c) > _CONST_MAX_BYTES):
+        _CONST.popitem(last=False)
+    _CONST[key] = c
     return c
 
 
@@ -164,9 +190,12 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     ready = prepare(0, state[None].expand(bsz, n_obj, 3))
     # ONE host sync per call (reference: one per look-ahead + 3 per step): the step counts travel to pinned memory behind the set-up, and the read of
     # the model's deferred numeric status — which synchronises the stream — completes both (one host round trip, ~75 us each on these boxes)
-    rep_host = _pinned(n_look, rep_max.dtype)
+    rep_host = _pinned(n_look, rep_max.dtype, device)
     rep_host.copy_(rep_max, non_blocking=True)
+    copied = torch.cuda.Event()
+    copied.record(torch.cuda.current_stream(torch.device(device)))
     model.take_status(device)
+    copied.synchronize()      # normally already complete (take_status synchronises the same stream); never rely on a subclass / stub doing so
     max_steps = rep_host.tolist()
     for li in range(n_look):
         if li > 0:
@@ -178,6 +207,7 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
                       _lib.AG_HEIGHT_MIN, None, raise_by, out=direct)
         if direct is None:
             seq[:, li] = res
+    _strict_status(model, device)
     return {"state_seqs": seq, "action_seqs": decoded}
 
 
@@ -217,4 +247,5 @@ def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer
     model.take_status(device)
     seq = rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr, repeat, n_steps, task["topk"],
                   task["connect_tools_all"], n_t, _lib.AG_HEIGHT_MASKED_MEAN, state_mask.bool(), raise_by)
+    _strict_status(model, device)
     return {"state_seqs": seq, "action_seqs": decoded}

@@ -152,7 +152,9 @@ class MPPIPlanner:
                                                    # chunks the ROLLOUT's memory: cost normaliser and softmax update still see all samples at once.
                                                    # The reference's chunked planner (rope.yaml:41-42: 20 000 in chunks of 500) is different: an
                                                    # independent Planner per chunk + merge_res — use mpc.Planner per chunk for those semantics.
-        self.model_rollout = lambda state, acts: dynamics_sharded(dynamics, state, acts, model, device, ppm_optimizer)
+        # copy=False (multi-GPU): a gathered result is a view of the cached receive buffer, valid until the next gather of the same shape —
+        # fine for one rollout scored right away, not for chunked rollouts that are concatenated afterwards
+        self.model_rollout = lambda state, acts, copy=True: dynamics_sharded(dynamics, state, acts, model, device, ppm_optimizer, copy=copy)
         self.evaluate_traj = functools.partial(running_cost, error_func=error_func, penalty_func=penalty_func, bbox=bbox)
 
     def sample(self, act_seq, iter_index, device=None):
@@ -170,7 +172,7 @@ class MPPIPlanner:
             parts = [self.model_rollout(state_cur, a) for a in act_seqs.split(self.n_sample_chunk)]
             out = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
         else:
-            out = self.model_rollout(state_cur, act_seqs)
+            out = self.model_rollout(state_cur, act_seqs, copy=False)
         reward = self.evaluate_traj(out["state_seqs"], act_seqs, state_cur=state_cur)["reward_seqs"]
         new_seq = optimize_action_mppi(act_seqs, reward, reward_weight=self.reward_weight, action_lower_lim=self.lo,
                                        action_upper_lim=self.hi, push_length=self.push_length)

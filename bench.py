@@ -67,6 +67,10 @@ DTYPE = {"f32": "f32 (exact fp32 MFMA)",
 # each under the power limit, tools/ubench/mx_mfma.hip) per 160 x 32 out-tile = 16.25 / 10
 EDGE_PRODUCTS = {"f32": 1, "bf16x3": 3, "fast": 1.625}
 DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16+fp8corr+bf16x3"}
+# <= 100 characters: the driver's record truncates longer config strings (the full description is the line's top-level "arithmetic")
+ARITH_SHORT = {"f32": "exact fp32 MFMA", "bf16x3": "fp32 as hi+lo bf16, 3 MFMAs per product, f32 accumulate",
+               "fast": "edge: f16 MFMA + scaled-fp8 corrections; node: bf16x3; Eterm q16; f32 accumulate"}
+assert all(len(v) <= 100 for v in ARITH_SHORT.values())
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -212,7 +216,8 @@ class Engine:
         timing = {} if self.world > 1 else None
 
         def one_pass(tm=None):
-            return agdist.dynamics_sharded(dynamics, state, action, self.model, self.dev, self.ppm, timing=tm)
+            # copy=False: the gathered states are consumed before the next pass, so the receive buffer is returned as is
+            return agdist.dynamics_sharded(dynamics, state, action, self.model, self.dev, self.ppm, timing=tm, copy=False)
 
         self.opt("precision", PRECISIONS[precision])
         self.opt("rollout_streams", streams)
@@ -326,6 +331,8 @@ def main():
                          "with fp8 corrections + q16 table; all three hold the 1e-4 gate at any motion size with model_status 0 "
                          "(tests/test_gpu_parity.py, tools/fuzz_parity.py)")
     ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
+    ap.add_argument("--cu-split", type=int, default=None,
+                    help="CUs (multiple of 8) of the MFMA partition of the CU-partitioned rollout, 0 = off (default: the engine's own choice)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -346,6 +353,8 @@ def main():
 
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz")))
     eng = Engine(args.material, weights, dev, world)
+    if args.cu_split is not None:
+        eng.opt("cu_split", args.cu_split)
     T = args.rollout_steps
     r = eng.run(args.batch, T, args.precision, args.streams, args.steps, args.warmup, profile=not args.no_profile,
                 global_batch=args.global_batch)
@@ -419,20 +428,23 @@ def main():
                        "global_batch": r["B_global"], "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather",
                        "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)" if args.weights == "seed0" else
                                   f"{args.weights} (the reference's train() on a toy dataset, tools/gen_trained.py)",
-                       "precision": args.precision, "arithmetic": DTYPE[args.precision],
+                       "precision": args.precision, "arithmetic": ARITH_SHORT[args.precision],
                        # 0 = no timed pass left the arithmetic's range (include/adaptigraph_hip.h: ag_model_status)
                        "model_status": r["model_status"]},
+            "arithmetic": DTYPE[args.precision],
             "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }
-        if extra:       # the driver's record keeps `config`, not `extra`: the per-mode throughputs and statuses of the same workload go here too
-            modes = {args.precision: {"value": line["value"], "model_status": r["model_status"]}}
-            for key, name in (("f32_mode", "f32"), ("bf16x3_mode", "bf16x3")):
+        if extra:       # the driver's record keeps the SCALAR keys of `config` only (nested dicts and `extra` are dropped, long strings cut):
+            cfg = line["config"]                                   # per-mode throughputs and statuses of the same workload as flat numbers
+            for key, name in (("f32_mode", "f32"), ("bf16x3_mode", "bf16x3"), ("trained_weights", "trained")):
                 if key in extra:
-                    modes[name] = {"value": extra[key]["value"], "model_status": extra[key]["model_status"]}
-            line["config"]["modes"] = modes
-            if "trained_weights" in extra:
-                line["config"]["trained_weights"] = {"value": extra["trained_weights"]["value"], "model_status": extra["trained_weights"]["model_status"]}
-            line["config"]["other_workloads"] = {k: {"value": v["value"], "model_status": v["model_status"]} for k, v in extra.get("workloads", {}).items()}
+                    cfg[f"{name}_value"] = round(extra[key]["value"], 1)
+                    cfg[f"{name}_status"] = extra[key]["model_status"]
+            for mat, v in extra.get("workloads", {}).items():
+                cfg[f"{mat}_value"] = round(v["value"], 1)
+                cfg[f"{mat}_status"] = v["model_status"]
+            if "value" in extra.get("mpc", {}):
+                cfg["mpc_ms"] = round(extra["mpc"]["value"], 2)
         if ranks:
             line["ranks"] = ranks
         if extra:

@@ -71,6 +71,10 @@ int ag_model_destroy(ag_model *m);
  *                            (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout call: 1 (default) =
  *                            where it pays (>= 32 768 node-rows x steps per call), 2 = always, 0 = never (once per node and model step).
  *                            Bit-identical results
+ *   "cu_split"         0|8k  CU-partitioned rollout (off by default): the first `cu_split` CU-mask bits (cu_split / 8 CUs of every XCD) run the
+ *                            MFMA-bound edge encoder, the other CUs the HBM-bound edge build / segment reduce / node update / state step, the batch
+ *                            parts pipelined through the two partitions on two CU-masked queues (hipExtStreamCreateWithCUMask).  Bit-identical
+ *                            results; measured NOT faster than sharing the chip (docs/NEGATIVE_RESULTS.md R5.1, profiles/r05_cu_split_sweep_rope.txt)
  *   "precision"        0/1/2 0 = exact fp32 MFMA; 1 = split-bf16 ("bf16x3": x = hi + lo, 3 bf16 MFMAs per product,
  *                            fp32 accumulate; 1e-6..8e-6 abs deviation from the reference forward, gate 1e-4);
  *                            2 (default) = mode 1 for the node-level stacks, the edge stack in fp16 with residual bytes ("edge_products" 2) and the
