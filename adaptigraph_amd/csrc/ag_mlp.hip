@@ -164,9 +164,10 @@ struct RowStoreEpi {        // one tile of the row-major [rows][160] table; row 
 //      epilogue (RowStoreQ16Epi) and the weight-stationary kernel's epilogue pieces, so both write the same bits. ------------------------------
 // largest |v| of two values against a running maximum (as a bit pattern; m >= 0).  NANSAFE: compared as unsigned integers — |x| orders
 // like one, and inf / NaN sort above every finite value, so a non-finite accumulator ends up in the block exponent and raises the
-// status bit (the split-bf16 edge stack has no other check).  Otherwise ONE v_max3_f32 with |.| source modifiers: a NaN is dropped, inf
-// is kept — the fp16 edge stack flags the activation that would produce a NaN here in the epilogue that made it (h3_pair).  Both
-// give the same maximum for finite tiles.  (Inline asm on accumulators: callers read them >= 4 MFMAs after their last write.)
+// status bit (the split-bf16 edge stack has no other check).  Otherwise ONE v_maximum3_f32 with |.| source modifiers (the IEEE-754-2019
+// maximum of gfx950: a NaN operand PROPAGATES, inf is kept; until r04 this was v_max3_f32, which drops a NaN — a NaN accumulator that no
+// activation check had caught was then stored as 0 with status 0): both flag the same tiles and give the same maximum for finite ones.
+// (Inline asm on accumulators: callers read them >= 4 MFMAs after their last write.)
 template <bool NANSAFE>
 __device__ __forceinline__ unsigned q16_max2(unsigned m, float a, float b)
 {
@@ -175,7 +176,7 @@ __device__ __forceinline__ unsigned q16_max2(unsigned m, float a, float b)
         return max(m, max(ua, ub));
     } else {
         unsigned r;
-        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+        asm("v_maximum3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
         return r;
     }
 }
@@ -185,7 +186,7 @@ __device__ __forceinline__ int q16_tile_exp(unsigned m, bool &nonfinite)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 sw = __builtin_amdgcn_permlane32_swap(m, m, false, false);
     m = max(sw.x, sw.y);
-    nonfinite = m >= 0x7f000000u;               // >= 2^127, inf or NaN: cannot be scaled into [-1, 1)
+    nonfinite = m >= 0x7e800000u;               // biased exponent > AG_Q16_EB_MAX (|v| >= 2^126), inf or NaN: the clamped scale would saturate the tile
     const int eb = (int)(m >> 23);
     return eb < AG_Q16_EB_MIN ? AG_Q16_EB_MIN : (eb > AG_Q16_EB_MAX ? AG_Q16_EB_MAX : eb);
 }
@@ -258,20 +259,50 @@ struct ZeroInit {
 };
 struct ResidInit {  // accumulator := Pn + h, i.e. W_pp[:, :F].enc + b_pp + residual (model.py:36-40,299-301).  Each source is either a
                     // packed (fragment-image) table, pointer already offset to this wave's 32-row block and this lane's (h, j), or — node
-                    // de-duplication — a row-major row of a compact table, pointer = row + 4h
+                    // de-duplication — a row-major row of a compact table, pointer = row + 4h.
+                    // The loads run ahead of their use (r05; loaded where a tile needs them, each of the layer's five tiles waited a full memory
+                    // latency two MFMAs into its chain): prefetch() issues h of ALL five out-tiles and Pn of tile 0 at the row tile's top (h's
+                    // registers are the ones the layer's output image occupies tile by tile: disjoint live ranges), operator()(ti) adds what
+                    // has arrived and issues Pn of tile ti + 1.  Measured -2.6 % (node_update is bound by bytes through L2, not by these
+                    // latencies: docs/NEGATIVE_RESULTS.md R5.2).
     const float *pn, *hh;
     bool pn_rowmajor, h_rowmajor;
+    mutable f32x16 hraw[AG_NT];       // h of all five out-tiles, issued at the row tile's top
+    mutable f32x16 pnext;             // Pn of the NEXT out-tile
+    __device__ __forceinline__ static void load_tile(const float *p, bool rowmajor, int ti, f32x16 &d)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // ONE unconditional 16-byte load per quad (address by select; a load under `if (rowmajor)` is split into predicated dword loads)
+            const int off = ((ti * 4 + q) * 2) * 128, offr = 32 * ti + 8 * q;
+            const bool pad = offr >= 152;                             // row-major rows: columns >= 152 + 4h are not read (zero)
+            const float4 a = *reinterpret_cast<const float4 *>(p + (rowmajor ? (pad ? 0 : offr) : off));
+            d[4 * q + 0] = a.x; d[4 * q + 1] = a.y; d[4 * q + 2] = a.z; d[4 * q + 3] = a.w;      // (padding quad: zeroed where the tile is consumed, zero_pad)
+        }
+    }
+    __device__ __forceinline__ static void zero_pad(bool rowmajor, int ti, f32x16 &d)      // a VALU op on a loaded value waits for the load: not in load_tile
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (32 * ti + 8 * q >= 152 && rowmajor) { d[4 * q + 0] = 0.f; d[4 * q + 1] = 0.f; d[4 * q + 2] = 0.f; d[4 * q + 3] = 0.f; }
+    }
+    __device__ __forceinline__ void prefetch() const
+    {
+#pragma unroll
+        for (int t = 0; t < AG_NT; ++t) load_tile(hh, h_rowmajor, t, hraw[t]);
+        load_tile(pn, pn_rowmajor, 0, pnext);
+    }
     __device__ __forceinline__ f32x16 operator()(int ti) const
     {
         f32x16 acc;
+        // opaque: without it the scheduler pulls this add up into the PREVIOUS out-tile, right behind the load (to free the register), where it
+        // waits for the load — and, vmcnt being in order, for whatever else was issued before it
+        asm volatile("" : "+v"(pnext));
+        zero_pad(pn_rowmajor, ti, pnext);
+        zero_pad(h_rowmajor, ti, hraw[ti]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int off = ((ti * 4 + q) * 2) * 128, offr = 32 * ti + 8 * q;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (pn_rowmajor) { if (offr < 152) a = *reinterpret_cast<const float4 *>(pn + offr); } else a = *reinterpret_cast<const float4 *>(pn + off);
-            if (h_rowmajor) { if (offr < 152) b = *reinterpret_cast<const float4 *>(hh + offr); } else b = *reinterpret_cast<const float4 *>(hh + off);
-            acc[4 * q + 0] = a.x + b.x; acc[4 * q + 1] = a.y + b.y; acc[4 * q + 2] = a.z + b.z; acc[4 * q + 3] = a.w + b.w;
-        }
+        for (int r = 0; r < 16; ++r) acc[r] = pnext[r] + hraw[ti][r];
+        if (ti + 1 < AG_NT) load_tile(pn, pn_rowmajor, ti + 1, pnext);
         return acc;
     }
 };
@@ -304,8 +335,8 @@ struct PrecF32 {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const float *buf = P.lds + P.buf * AG_CHUNK_FLOATS;
+            f32x16 acc = init(ti);      // BEFORE the chunk DMA: vmcnt retires in order, so a wait for a load issued behind the DMA waits for the DMA too
             pipe_dma(P, P.buf ^ 1);
-            f32x16 acc = init(ti);
 #pragma unroll
             for (int m = 0; m < PT; ++m) {
                 const int t = m / 4, q = m % 4;
@@ -420,8 +451,8 @@ struct PrecB3 {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
             const unsigned la = lds_addr_of(P.lds) + (unsigned)(P.buf * AG_CHUNK_FLOATS * 4 + lane * 16);
+            f32x16 acc = init(ti);      // BEFORE the chunk DMA: vmcnt retires in order, so a wait for a load issued behind the DMA waits for the DMA too
             pipe_dma(P, P.buf ^ 1);
-            f32x16 acc = init(ti);
             bf16x8 wq[PF + 1][2];
             static_for<0, (PF < NU ? PF : NU)>([&](auto U) {
                 constexpr int u = decltype(U)::value;
@@ -1268,6 +1299,13 @@ __global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a)
     float4 *dst = reinterpret_cast<float4 *>(a.edge_node_tab + (size_t)g * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    // Non-finite raw inputs raise the status bit HERE: the weight-stationary kernel builds its first-layer operands without the range check the
+    // streaming kernel applies to them (h3_pair<true>), and a NaN that reaches a hidden activation with its sign bit set is ReLU'd to 0.
+    // (A finite difference beyond fp16's range becomes +-inf there and is caught by the hidden layers' own check.)
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += o[k] * 0.0f;      // 0 for finite rows, NaN otherwise
+    if (a.status && !(sum == 0.0f)) atomicOr(a.status, 1);
 }
 
 // First layer of one 32-edge block for out-tiles [T0, T0 + NT): per tile 2 k16-steps x (lo, hi) fp16 MFMAs with the A fragments read from the
@@ -1588,6 +1626,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         const int nb = gridDim.x, bid = blockIdx.x, qq = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
         q.tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
+    f32x16 agg_next[AG_NT];      // (!FUSE) the agg rows of the row tile about to start
+    bool have_next = false;
 #pragma unroll 1
     while (q.tile < ntiles) {
         const int tile = q.tile;
@@ -1632,19 +1672,40 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                 __syncthreads();
             }
         } else {
-            f32x16 agg[AG_NT];
-            load_rowmajor(a.agg + (size_t)gc * AG_FP, agg, h);
-#pragma unroll
-            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg[t]);
+            // this row tile's agg rows: loaded during the PREVIOUS row tile's last two layers (below), except for a workgroup's first tile
+            if (!have_next) load_rowmajor(a.agg + (size_t)gc * AG_FP, agg_next, h);
         }
         const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         // Pn (+ h in round 0) come from the compact rows of the de-duplicated node encoder when it is on
         const size_t crow = a.pn_rows ? (size_t)a.node_row[gc] * AG_FP + 4 * h : 0;
         const ResidInit resid{a.pn_rows ? a.pn_rows + crow : a.pn + blk, a.h_rows ? a.h_rows + crow : a.h + blk, a.pn_rows != nullptr, a.h_rows != nullptr};
+        resid.prefetch();      // issued before the operand split of agg below, whose ~250 VALU instructions cover part of the latency
+        if constexpr (!FUSE) {
+#pragma unroll
+            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg_next[t]);
+        }
+        // The next row tile of this workgroup (static grid stride: TileQueue without a counter): its agg rows are fetched while this tile's second
+        // and third layers run, into the registers the first layer's input image has just left.
+        const int tile_n = tile + (int)gridDim.x;
+        auto prefetch_agg = [&]() {
+            if constexpr (!FUSE) {
+                have_next = tile_n < ntiles;       // workgroup-uniform
+                if (have_next) {
+                    const int gn = tile_n * AG_ROWS_PER_BLOCK + wave * 32 + j;
+                    load_rowmajor(a.agg + (size_t)(gn < Mn ? gn : 0) * AG_FP, agg_next, h);
+                } else {      // (a defined value on this path too: otherwise the previous tile's rows stay live through the whole first layer)
+#pragma unroll
+                    for (int t = 0; t < AG_NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) agg_next[t][r] = 0.0f;
+                }
+            }
+        };
         if (!LAST) {
             dense<Prec, AG_F, true, false>(P, x, y, resid, PackStoreEpi{a.h + blk});   // h'
             q.publish();
+            prefetch_agg();
             // Hr/Hs of the NEXT round go to the alternate tables: other workgroups of this launch may still be
             // gathering this round's Hs rows (fused aggregation reads them inside this kernel).
             dense_store<Prec, AG_F, false, false>(P, y, ZeroInit{}, RowStoreEpi{a.hr_out + rowoff});
@@ -1655,6 +1716,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             q.publish();
             dense<Prec, AG_F, true, true>(P, y, x, ZeroInit{});    // linear_0 + ReLU
             dense<Prec, AG_F, true, true>(P, x, y, ZeroInit{});    // linear_1 + ReLU
+            prefetch_agg();                                        // (both activation images are live until here: the decoder ping-pongs them)
             f32x16 m;
             Prec::template layer<AG_F, 1, false, true>(P, y, ZeroInit{}, NoEpi{},      // linear_2 -> rows 0..2 of tile 0
                                                        [&](int, const f32x16 &v) { m = v; });

@@ -311,6 +311,48 @@ class Engine:
         return {"roofline": roof, "roofline_hbm": roof_hbm, "kernels": kernels}
 
 
+def stub_dynamics(state, action, *_args, **_kw):
+    """--dry-run stand-in for the engine (CPU, no GPU needed): the result depends only on the sample's action, so the sharded / gathered
+    result can be checked against the unsharded call (tests/test_host_logic.py)."""
+    seq = action[:, :, :3].sum(-1)[:, :, None, None] + state[None, None]
+    return {"state_seqs": seq.float(), "action_seqs": action * 2.0}
+
+
+class DryEngine(Engine):
+    """bench.py --dry-run: everything of an N-rank run EXCEPT the engine — process group (gloo, CPU tensors), batch sharding, the all-gather,
+    the max-over-ranks timing and the JSON line — so the launch line, argument and key contract of the SCALE run can be exercised without
+    GPUs.  Its numbers mean nothing and the line says so ("data": "dry-run")."""
+
+    def __init__(self, material, dev, world):
+        self.material, self.dev, self.world = material, dev, world
+
+    def opt(self, name, value):
+        pass
+
+    def sync(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None):
+        wl = WORKLOADS[self.material]
+        B_global = batch * self.world if global_batch is None else global_batch
+        state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
+        state, action = torch.from_numpy(state_np), torch.from_numpy(act_np)
+        t_roll = t_gather = 0.0
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a = time.perf_counter()
+            out = agdist.dynamics_sharded(stub_dynamics, state, action, copy=False)
+            t_roll += time.perf_counter() - a
+        self.sync()
+        dt = time.perf_counter() - t0
+        full = stub_dynamics(state, action)
+        assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and torch.equal(out["state_seqs"], full["state_seqs"])
+        return {"B_global": B_global, "dt": dt, "ms_per_step": dt / steps * 1e3, "value": B_global * T * steps / dt, "roofline": None,
+                "roofline_hbm": None, "kernels": None, "model_status": 0, "rank_ms": (t_roll / steps * 1e3, t_gather / steps * 1e3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +373,9 @@ def main():
                          "with fp8 corrections + q16 table; all three hold the 1e-4 gate at any motion size with model_status 0 "
                          "(tests/test_gpu_parity.py, tools/fuzz_parity.py)")
     ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no engine: process group on gloo with CPU tensors, sharding, all-gather, timing reduction and the JSON line only "
+                         "(launch-line / key contract of the multi-GPU run; the numbers are meaningless)")
     ap.add_argument("--cu-split", type=int, default=None,
                     help="CUs (multiple of 8) of the MFMA partition of the CU-partitioned rollout, 0 = off (default: the engine's own choice)")
     args = ap.parse_args()
@@ -339,20 +384,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the engine has no CPU fallback)"
-    local %= max(1, torch.cuda.device_count())       # (a box with fewer GPUs than ranks — the 2-rank test on one GPU — wraps around)
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AG_DIST_BACKEND", "nccl")             # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend)
+    if args.dry_run:
+        dev = "cpu"
+        args.no_profile = args.no_extra = args.no_cpu_baseline = True
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the engine has no CPU fallback)"
+        local %= max(1, torch.cuda.device_count())       # (a box with fewer GPUs than ranks — the 2-rank test on one GPU — wraps around)
+        torch.cuda.set_device(local)
+        dev = f"cuda:{local}"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("AG_DIST_BACKEND", "nccl")             # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(dev))
+            else:
+                dist.init_process_group(backend)
 
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz")))
-    eng = Engine(args.material, weights, dev, world)
+    eng = DryEngine(args.material, dev, world) if args.dry_run else Engine(args.material, weights, dev, world)
     if args.cu_split is not None:
         eng.opt("cu_split", args.cu_split)
     T = args.rollout_steps
@@ -420,7 +472,7 @@ def main():
             "value": r["B_global"] * T * args.steps / dt, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.global_batch is None else "strong",
-            "vs_baseline": None, "dtype": DTYPE_TOKEN[args.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_TOKEN[args.precision], "data": "dry-run (no engine: contract check only)" if args.dry_run else "synthetic",
             "config": {"workload": f"{args.material} {wl['n_obj']}+tool particles, batch {per_gpu}/GPU, "
                                    f"{T}-step rollout (BASELINE configs[1])" if args.material == "rope" else
                                    f"{args.material} {wl['n_obj']} particles, batch {per_gpu}/GPU"

@@ -31,7 +31,7 @@ from adaptigraph_amd import _lib, configs, losses, mpc, synth          # noqa: E
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
 
 
-def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1, chunk=None, streams=None):
+def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1, chunk=None, streams=None, dry=False):
     """Time `steps` MPPI iterations (sample -> sharded rollout -> chamfer/penalty cost -> softmax update) on this rank's GPU.
     Returns (ms per iteration measured on this rank, last reward tensor)."""
     import time
@@ -46,19 +46,29 @@ def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup
     target = (state + np.array([0.4, 0.0, 0.3], np.float32)).astype(np.float32)
     bbox = np.array([[state[:, 0].min() - 5, state[:, 0].max() + 5], [state[:, 2].min() - 5, state[:, 2].max() + 5]])
     g = torch.Generator().manual_seed(0)
-    model = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), dev)
-    with torch.no_grad():
-        for p in model.parameters():
-            p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
-    model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[precision])
-    if streams is not None:
-        model.set_option("rollout_streams", streams)
     ppm = configs.ppm_optimizer_stub(mat)
     ppm.physics_param = {mat: torch.tensor([0.5], device=dev)}
     state_t, target_t = torch.from_numpy(state).to(dev), torch.from_numpy(target).to(dev)
-    planner = mpc.MPPIPlanner(model, dev, ppm, partial(losses.chamfer, y=target_t[None]),
+    if dry:      # --dry-run: no engine, no GPU — sampling, sharding, the all-gather and the MPPI update on CPU tensors with a stand-in rollout and cost
+        model, error = None, (lambda s: (s - target_t[None]).square().sum(-1).mean(-1))
+    else:
+        model = DynamicsPredictor(configs.model_config(), configs.material_config(mat), configs.dataset_config(mat), dev)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.copy_(torch.empty_like(p).uniform_(-1, 1, generator=g) / np.sqrt(p.shape[-1]))
+        model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[precision])
+        if streams is not None:
+            model.set_option("rollout_streams", streams)
+        error = partial(losses.chamfer, y=target_t[None])
+    planner = mpc.MPPIPlanner(model, dev, ppm, error,
                               partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
                               n_sample=samples, n_update_iter=1, rollout_best=False, n_sample_chunk=chunk)
+    if dry:
+        from adaptigraph_amd.dist import dynamics_sharded
+
+        def stub(st, acts):
+            return {"state_seqs": (acts[:, :, :3].sum(-1)[:, :, None, None] * 1e-3 + st[None, None]).float(), "action_seqs": acts * 2.0}
+        planner.model_rollout = lambda st, acts, copy=True: dynamics_sharded(stub, st, acts, copy=copy)
     act_seq = torch.from_numpy(act[0]).to(dev)
 
     def one_iteration(seq, it):
@@ -68,10 +78,12 @@ def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup
         return new_seq, reward
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     seq = act_seq
     for i in range(warmup):
@@ -96,23 +108,32 @@ def main():
     ap.add_argument("--chunk", type=int, default=None, help="evaluate the samples in chunks of this size, as the reference planner does "
                                                           "(config/planning/rope.yaml: n_sample 20000, n_sample_chunk 500); default: one rollout")
     ap.add_argument("--streams", type=int, default=None, help="rollout_streams engine option (default: the engine's choice)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU, no engine: gloo process group on CPU tensors, sampling / sharding / all-gather / MPPI "
+                                                             "update and the JSON line only (contract check; the number is meaningless)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench_mpc.py needs an MI355X: the engine has no CPU path")
-    local %= max(1, torch.cuda.device_count())       # fewer GPUs than ranks (2-rank test on one GPU): wrap around
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AG_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    _lib.lib()
-    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world, a.chunk, a.streams)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.dry_run:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench_mpc.py needs an MI355X: the engine has no CPU path")
+        local %= max(1, torch.cuda.device_count())       # fewer GPUs than ranks (2-rank test on one GPU): wrap around
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("AG_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; tests on a 1-GPU box use "gloo"
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+        _lib.lib()
+    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world, a.chunk, a.streams, dry=a.dry_run)
     tt = torch.tensor([per_it], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -122,7 +143,8 @@ def main():
         print(json.dumps({
             "metric": "MPPI iteration wall-clock (sample + rollout + cost + update)", "value": round(per_it, 3), "unit": "ms",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(per_it, 3),
-            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": a.precision,
+            "data": "dry-run (no engine: contract check only)" if a.dry_run else "synthetic",
             "graph_steps_per_s": round(a.samples * a.push_steps / per_it * 1e3, 1),
             "config": {"workload": f"rope-{a.particles}+1 MPPI: {a.samples} samples x {a.push_steps}-step rollout, chamfer "
                                    f"cost to a {a.particles}-point target", "samples": a.samples, "push_steps": a.push_steps,

@@ -5,6 +5,7 @@ Bars: edge lists bit-exact; fp32 outputs within 1e-4 max-abs of the reference fo
 (BASELINE.json north_star); measured deviation is ~1e-6, the tolerances below keep a margin but would catch
 any structural error (a wrong edge or column block moves outputs by >= 1e-2).
 """
+import os
 import warnings
 
 import numpy as np
@@ -21,8 +22,9 @@ from oracle import ag_oracle as ago
 pytestmark = pytest.mark.gpu
 TOL_FWD = 1e-4        # north_star gate (single forward, identical graphs)
 TOL_TIGHT = 2e-5      # 5x inside the gate: exact-fp32 mode measures ~1e-7..1e-6, split-bf16 mode ~1e-6..6e-6
-TOL_BY_PREC = {"f32": 2e-5, "bf16x3": 2e-5, "fast": 2e-5}   # gate 1e-4; since r04 "fast" (q16 Eterm table + fp16 edge stack with residual bytes) is in the
-                                                             # split-bf16 mode's class: measured values in profiles/r04_fwd_err.txt
+TOL_BY_PREC = {"f32": 2e-5, "bf16x3": 2e-5, "fast": 4e-5}   # gate 1e-4.  "fast" (q16 Eterm table + fp16 edge stack with residual bytes) measures <= 1.87e-5
+                                                             # (scaled-decoder clamp golden; the others <= 6e-6, profiles/r04_fwd_err.txt): 2x margin over
+                                                             # the measured worst case, so a toolchain scheduling change cannot flip a test 2.5x inside the gate
 DEV = "cuda:0"
 
 
@@ -558,10 +560,98 @@ def test_rollout_at_the_benchmarked_config_vs_oracle(material, n_obj, batch, ste
     # exact-fp32 mode: inside the gate after all steps, or — granular-2k saturates its top-20 with candidates a few 1e-7 apart — a PROVEN
     # top-k near-tie (explain_divergence raises unless the first differing edge list differs only by such candidates); no drift allowance
     assert prec != "f32" or material == "granular" or (err <= TOL_FWD).all(), err
-    for b in np.nonzero(err > TOL_FWD)[0]:      # 10-20 steps: per-step parity on identical graphs is the gate, the accumulated drift is reported
-        step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=(prec != "f32"))
-        print(f"{material} {prec} sample {pick[b]}: rollout drift {err[b]:.2e} after {steps} steps; max one-step deviation on identical graphs {dev:.2e}"
-              + (f"; top-k near-tie at step {step} (candidates {gap:.2e} apart)" if step else "; edge lists equal the reference's at every step"))
+    record = os.environ.get("AG_DRIFT_FILE")    # evidence runs (tools/evidence_r05.sh): the measured drift is RECORDED, one line per sample
+    for b in (range(len(pick)) if record else np.nonzero(err > TOL_FWD)[0]):      # 10-20 steps: per-step parity on identical graphs is the gate
+        if err[b] > TOL_FWD:
+            step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=(prec != "f32"))
+        else:       # inside the gate after all steps: nothing to prove; the one-step deviations are measured for the record only
+            try:
+                step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=True)
+            except AssertionError as e:      # (a proven near-tie that healed, or a tie explain_divergence cannot classify: not a failure inside the gate)
+                step, dev, gap = None, float("nan"), 0.0
+                print("note:", e)
+        line = (f"{material} {n_obj} x {batch} x {steps} steps | {prec:6s} | sample {pick[b]:3d} | final-state drift vs the reference rollout {err[b]:.2e}"
+                f" | max one-step deviation on identical graphs {dev:.2e} | "
+                + (f"top-k near-tie at step {step} (candidates {gap:.2e} apart)" if step else "edge lists equal the reference's at every step"))
+        print(line)
+        if record:
+            with open(record, "a") as f:
+                f.write(line + "\n")
+
+
+def test_rollout_at_the_global_batch_of_configs3(weights):
+    """BASELINE configs[3] at its GLOBAL batch on one GPU: cloth-4k, batch 512, 20-step rollout (8 GPUs would run 64 each).  The first and the
+    last per-GPU share (64 samples each) rolled out alone equal their rows of the 512-batch result bit for bit, and two samples are held
+    against the oracle's rollout like the per-GPU share in test_rollout_at_the_benchmarked_config_vs_oracle."""
+    material, n_obj, batch, steps = "cloth", 4096, 512, 20
+    state, act = synth.make_mpc_inputs(material, n_obj, batch, seed=34, len_lo=steps, len_hi=steps + 0.9)
+    pick = [0, batch - 1]
+    for k, b in enumerate(pick):
+        act[b, 0, 0], act[b, 0, 1] = state[(k * 997) % n_obj, 0], state[(k * 997) % n_obj, 2]
+    m = make_model(weights, material, prec="fast")
+    full = dynamics(t(state), t(act), m, DEV, _ppm(material))["state_seqs"]
+    assert m.take_status() == 0 and full.shape == (batch, 1, n_obj, 3) and torch.isfinite(full).all()
+    for lo in (0, batch - 64):
+        share = dynamics(t(state), t(act[lo:lo + 64]), m, DEV, _ppm(material))["state_seqs"]
+        assert torch.equal(full[lo:lo + 64], share), "a per-GPU share must equal its rows of the global batch"
+    ref, _ = ago.dynamics(weights, configs.task_config(material), state, act[pick])
+    err = np.abs(full[pick].cpu().numpy() - ref).reshape(len(pick), -1).max(1)
+    for b in np.nonzero(err > TOL_FWD)[0]:
+        step, dev, gap = explain_divergence(m, weights, material, state, act[pick], int(b), allow_drift=True)
+        print(f"cloth 512 x 20 sample {pick[b]}: drift {err[b]:.2e}, max one-step deviation {dev:.2e}, near-tie step {step}")
+
+
+@pytest.mark.parametrize("bad", ["nan", "-nan", "inf", "-inf"])
+def test_nonfinite_inputs_raise_the_status_in_both_edge_kernels(weights, bad):
+    """The weight-stationary and the streaming edge encoder are bit-identical AND report alike: a non-finite position in a particle that
+    has edges raises status bit 0 with either kernel (the weight-stationary kernel's table maximum dropped NaNs and built its
+    first-layer operands without a range check, so a NaN could end as a stored 0 with status 0)."""
+    g = synth.make_graph_inputs("rope", 200, 2, seed=9, spacing=0.1)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)   # graph from the clean cloud
+    val = {"nan": np.float32(np.nan), "-nan": -np.float32(np.nan), "inf": np.float32(np.inf), "-inf": -np.float32(np.inf)}[bad]
+    st = g["state"].copy()
+    st[1, -1, 57, 1] = val                     # current frame of one particle of sample 1
+    m = make_model(weights, prec="fast")
+    kw = dict(action=t(g["action"]), rope_physics_param=t(g["phys"]))
+    flags = []
+    for ws in (0, 1):
+        m.set_option("edge_stationary", ws)
+        m.take_status()
+        import warnings as w
+        with w.catch_warnings():
+            w.simplefilter("ignore")
+            _, mot = m(t(st), t(g["attrs"]), csr, None, t(g["p_instance"]), **kw)
+            flags.append(m.take_status() & 1)
+        assert torch.isfinite(mot[0]).all()    # the other sample is untouched
+    assert flags == [1, 1], flags
+    m.set_option("edge_stationary", 1)
+    _, clean = m(t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]), **kw)
+    assert m.take_status() == 0 and torch.isfinite(clean).all()
+
+
+def test_strict_status_raises_in_the_call_that_caused_it(weights, monkeypatch):
+    """AG_STRICT_STATUS=1: dynamics() reads the numeric status at its END and raises (default: the next call's read warns — sync-free)."""
+    big = {k: v.copy() for k, v in weights.items()}
+    for k in ("relation_encoder.model.0.weight", "relation_encoder.model.0.bias", "relation_encoder.model.2.weight"):
+        big[k] *= 1.0e3                                          # a hidden fp16 activation beyond 65504 (see the overflow test below)
+    state, act = synth.make_mpc_inputs("rope", 100, 4, seed=1, len_lo=2, len_hi=3.9, spacing=0.1)
+    act[:, 0, 0], act[:, 0, 1] = state[50, 0], state[50, 2]
+    m = make_model(big, prec="fast")
+    monkeypatch.setenv("AG_STRICT_STATUS", "1")
+    with pytest.raises(FloatingPointError):
+        dynamics(t(state), t(act), m, DEV, _ppm("rope"))
+    assert m.take_status() == 0                                  # consumed by the raising call
+    ok = make_model(weights, prec="fast")
+    out = dynamics(t(state), t(act), ok, DEV, _ppm("rope"))["state_seqs"]
+    assert torch.isfinite(out).all()
+    monkeypatch.delenv("AG_STRICT_STATUS")
+    import warnings as w
+    with w.catch_warnings(record=True) as rec:                   # default: deferred by one call, as a warning
+        w.simplefilter("always")
+        dynamics(t(state), t(act), m, DEV, _ppm("rope"))
+        assert not any("non-finite" in str(x.message) for x in rec)
+        dynamics(t(state), t(act), m, DEV, _ppm("rope"))
+        assert any("non-finite" in str(x.message) for x in rec)
 
 
 def test_rollout_is_hip_graph_capturable(weights):

@@ -111,6 +111,12 @@ def _gloo_worker(rank, world, port, total, q):
         out2 = agdist.dynamics_sharded(fake_dynamics, state, action + 1.0, "x")
         full2 = fake_dynamics(state, action + 1.0, "x")
         ok = ok and all(torch.equal(out2[k], full2[k]) for k in full2) and all(torch.equal(out[k], full[k]) for k in full)
+        # copy=False (bench / MPPI path): views of the cached receive buffers — right contents, one buffer per key, overwritten by the next gather
+        out3 = agdist.dynamics_sharded(fake_dynamics, state, action + 2.0, "x", copy=False)
+        full3 = fake_dynamics(state, action + 2.0, "x")
+        ok = ok and all(torch.equal(out3[k], full3[k]) for k in full3) and out3["state_seqs"].data_ptr() != out3["action_seqs"].data_ptr()
+        out4 = agdist.dynamics_sharded(fake_dynamics, state, action + 3.0, "x", copy=False)
+        ok = ok and out4["state_seqs"].data_ptr() == out3["state_seqs"].data_ptr() and all(torch.equal(out2[k], full2[k]) for k in full2)
         # replicated-input contract: per-rank draws differ until replicate() broadcasts rank 0's (MPPI samples)
         torch.manual_seed(100 + rank)
         draw = torch.rand(total, 2, 4)
@@ -151,3 +157,42 @@ def test_dynamics_sharded_gloo_world4_and_8(world, total):
     """The SCALE run's shapes before the first real RCCL contact: BASELINE configs[4]'s 1024 samples over 8 ranks (even), 500 over 8
     (uneven: seven shards of 63 and one of 59), fewer samples than ranks (empty shards), and a 4-rank uneven split."""
     _run_gloo(world, total)
+
+
+def _torchrun(script, n, extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29100 + (os.getpid() * 13 + n * 7 + len(extra)) % 700
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, script), "--gpus", str(n), "--dry-run"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    return json.loads(lines[0])
+
+
+def test_bench_dry_run_world8_strong_scaling_contract():
+    """The driver's launch line for the SCALE run, N = 8, BASELINE configs[3] in its strong-scaling form (--global-batch 512): process group,
+    sharding, all-gather, max-over-ranks timing and the JSON line with everything but the engine (bench.py --dry-run: gloo, CPU tensors, a
+    stand-in rollout whose gathered result is checked against the unsharded one inside the run).  No GPU, no number: the key contract only."""
+    d = _torchrun("bench.py", 8, ["--steps", "2", "--warmup", "0", "--material", "cloth", "--global-batch", "512", "--rollout-steps", "20"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "graph-steps/s" and d["data"].startswith("dry-run")
+    cfg = d["config"]
+    assert cfg["global_batch"] == 512 and cfg["rollout_steps"] == 20 and cfg["parallelism"] == "batch-shard x8 + all-gather"
+    assert "batch 64/GPU" in cfg["workload"] and "global batch 512 over 8 GPUs" in cfg["workload"]
+    assert all(isinstance(v, (int, float, str)) and (not isinstance(v, str) or len(v) <= 100) for v in cfg.values()), "flat, short config values"
+    assert set(d["ranks"]) >= {"ms_per_step", "rollout_ms", "all_gather_ms"} and d["ranks"]["ms_per_step"]["max"] >= d["ranks"]["ms_per_step"]["min"]
+    assert abs(d["value"] - 512 * 20 * 2 / (d["ms_per_step"] * 2 / 1e3)) <= 1e-6 * d["value"]
+
+
+def test_bench_dry_run_world8_weak_scaling_and_mpc_contract():
+    """Weak-scaling form (the driver's default: per-GPU batch fixed) and bench_mpc.py (BASELINE configs[4]: 1024 samples over 8 ranks)."""
+    d = _torchrun("bench.py", 8, ["--steps", "1", "--warmup", "0", "--batch", "4"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 and "batch 4/GPU" in d["config"]["workload"]
+    m = _torchrun("bench_mpc.py", 8, ["--steps", "1", "--warmup", "1", "--samples", "1024", "--particles", "50"])
+    assert m["n_gpus"] == 8 and m["scaling"] == "strong" and m["higher_is_better"] is False and m["unit"] == "ms"
+    assert m["config"]["samples"] == 1024 and m["config"]["parallelism"] == "samples/8" and m["value"] > 0
