@@ -19,6 +19,7 @@ constexpr int kNodesPerBlock = 6;   // 6 nodes x 40 float4 columns = 240 of 256 
 
 __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 {
+    ag_overflow_view(a);
     // XCD-aware block -> node-range mapping: the dispatcher puts block b on XCD b % 8 (MI355X_MICROARCH.md
     // §Workgroup dispatch); give each XCD a contiguous range of nodes (= whole graphs) so the gathered
     // Hs rows of a graph stay in ONE XCD's L2 instead of being replicated in all eight.
@@ -70,6 +71,7 @@ constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 template <bool HSQ>
 __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 {
+    ag_overflow_view(a);
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

@@ -342,11 +342,13 @@ FwdLayout fwd_layout(int B, int N, int64_t e_cap)
     FwdLayout L;
     L.rows_pad = align_up((size_t)B * N, AG_ROWS_PER_BLOCK);
     L.e_pad = align_up((size_t)(e_cap > 0 ? e_cap : 1), 256);   // whole row tiles of either edge encoder (128 / 256 edges)
-    L.rows_c = align_up((size_t)B * (N + AG_DEDUP_REPS), AG_ROWS_PER_BLOCK);      // compact rows of the de-duplicated node encoder (worst case: all private)
+    // compact rows of the de-duplicated node encoder: AG_DEDUP_REPS shared rows per sample + a bounded private budget (the reference's drivers
+    // use 2 rows per sample; until r04 this was sized for "every node private": 4 x B (N + 8) rows, 10.7 GB at the planner's 20 000 x 200)
+    L.rows_c = align_up((size_t)B * AG_DEDUP_REPS + std::max<size_t>((size_t)B * N / 16, 1024), AG_ROWS_PER_BLOCK);
     return L;
 }
 
-void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
+void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap, bool eterm16 = false)
 {
     const FwdLayout L = fwd_layout(B, N, e_cap);
     const size_t rc = L.rows_c + AG_ROWS_PER_BLOCK;              // + dump rows of the encoder's out-of-range lanes
@@ -366,10 +368,15 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap)
     a.send_c = c.take<int32_t>(L.e_pad);
     a.rows_c = (int)L.rows_c;
     a.agg = c.take<float>(L.rows_pad * AG_FP);
-    a.eterm = c.take<float>(L.e_pad * AG_FP);
+    // per-edge table: fp32 rows (640 B), or — sized for a model in precision mode 2 (ag_*_workspace_bytes_for) — q16 rows (320 B) + the
+    // weight-stationary kernel's dump rows behind them
+    a.eterm = eterm16 ? c.take<float>((L.e_pad + 256) * (AG_FP / 2)) : c.take<float>(L.e_pad * AG_FP);
     a.edge_node_tab = c.take<float>(L.rows_pad * 16);
     a.tile_ctr = c.take<int>(AG_TILE_CTRS);
     a.enc_count = a.tile_ctr + 1;                                // (zeroed by run_node_encode before the classification fills the work list)
+    a.priv_count = a.tile_ctr + 2;
+    a.ovf = a.tile_ctr + 3;
+    a.shared_rows = B * AG_DEDUP_REPS;
 }
 
 void carve_edges(Carver &c, AgEdgeArgs &a)
@@ -422,7 +429,8 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
     a.edge_ws = m->edge_ws;
     a.dedup = m->node_dedup && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&
               (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
-    a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr;
+    a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr; a.hr_full = nullptr; a.hs_full = nullptr;
+    if (!a.dedup) a.ovf = nullptr;
     {   // workgroups of the weight-stationary edge encoder (one per CU): a launch that shares the chip with the other rollout streams
         // takes 1.5x its share of the CUs, capped at all of them (two-stream rollout, C2, r04: 128 CUs -> 127.8 k, 160 -> 133.3 k, 192 -> 134.2 k, 224 -> 132.1 k,
         // 256 -> 132.0 k graph-steps/s)
@@ -437,8 +445,15 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
 // tables no later kernel overwrites — ag_rollout runs this ONCE per call instead of once per model step.
 void run_node_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
-    if (a.dedup) (void)hipMemsetAsync(a.enc_count, 0, sizeof(int), s);
+    if (a.dedup) (void)hipMemsetAsync(a.enc_count, 0, 3 * sizeof(int), s);      // enc_count, priv_count, ovf
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
+}
+
+// De-duplicated calls only: the per-node encoder behind a test of the overflow flag (a handful of workgroups that read one word and return,
+// unless this call's inputs did not fit the compact tables).  Every model step: the full-size tables it fills are overwritten by the rounds.
+void run_node_encode_fallback(ag_model *m, AgFwdArgs &a, hipStream_t s)
+{
+    if (a.dedup) ag_launch_node_encode_fallback(m->w, a, s);
 }
 
 void run_edge_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
@@ -454,6 +469,8 @@ void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
         if (a.dedup) {
             r.pn_rows = a.pnc;           // Pn: compact rows in every round
             if (p == 0) {                // round 0 reads the encoder's compact rows: Hr through node_row, Hs through send_c, h from h0c
+                r.hr_full = a.hr;        // (or, when the call overflowed the compact tables, the per-node encoder's full-size ones)
+                r.hs_full = a.hs;
                 r.hr = a.hrc;
                 r.hs = a.hsc;
                 r.hr_row = a.node_row;
@@ -474,6 +491,7 @@ void run_forward(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     setup_args(m, a, m->max_blocks);
     run_node_encode(m, a, s);
+    run_node_encode_fallback(m, a, s);
     run_edge_encode(m, a, s);
     run_propagate(m, a, s);
 }
@@ -853,11 +871,15 @@ int ag_build_edges(const float *pos, const uint8_t *mask, const uint8_t *tool_ma
     return AG_OK;
 }
 
-size_t ag_forward_workspace_bytes(int B, int N, int64_t e_cap)
+static bool table16(const ag_model *m) { return m && m->precision == AG_PREC_B3 && m->eterm_half; }      // precision mode 2: q16 rows (320 B)
+
+size_t ag_forward_workspace_bytes(int B, int N, int64_t e_cap) { return ag_forward_workspace_bytes_for(nullptr, B, N, e_cap); }
+
+size_t ag_forward_workspace_bytes_for(const ag_model *m, int B, int N, int64_t e_cap)
 {
     AgFwdArgs a{};
     Carver c(nullptr, 0);
-    carve_forward(c, a, B, N, e_cap);
+    carve_forward(c, a, B, N, e_cap, table16(m));
     return align_up(c.off, 256);
 }
 
@@ -879,7 +901,7 @@ int ag_forward(ag_model *m, const float *state, const float *attrs, const float 
     a.B = B; a.N = N; a.n_p = n_p; a.n_inst = n_instance; a.phys_dim = m->cfg.phys_dim; a.e_cap = (int)e_cap;
     a.pstep = m->cfg.pstep; a.clamp = m->cfg.motion_clamp;
     Carver c(workspace, workspace_bytes);
-    carve_forward(c, a, B, N, e_cap);
+    carve_forward(c, a, B, N, e_cap, table16(m));
     if (!c.ok()) return fail(AG_ERR_WS, "ag_forward: workspace %zu < %zu bytes", workspace_bytes, c.off);
     run_forward(m, a, static_cast<hipStream_t>(stream));
     AG_HIP(hipGetLastError());
@@ -887,7 +909,7 @@ int ag_forward(ag_model *m, const float *state, const float *attrs, const float 
 }
 
 static void carve_rollout(Carver &c, const ag_rollout_params *p, int B, AgFwdArgs &f, AgEdgeArgs &e, float **state,
-                          float **pred_pos, float **pred_motion, int n_his)
+                          float **pred_pos, float **pred_motion, int n_his, bool eterm16)
 {
     const int64_t e_cap = ag_edge_capacity(B, p->N, p->topk, p->connect_tools_all, p->max_tools);
     const size_t rows = (size_t)B * p->N;
@@ -900,7 +922,7 @@ static void carve_rollout(Carver &c, const ag_rollout_params *p, int B, AgFwdArg
     e.B = B; e.N = p->N; e.connect = p->connect_tools_all ? 1 : 0;
     edge_caps(p->N, p->topk, e.connect, p->max_tools, &e.cap0, &e.cap);
     carve_edges(c, e);
-    carve_forward(c, f, B, p->N, e_cap);
+    carve_forward(c, f, B, p->N, e_cap, eterm16);
     f.e_cap = (int)e_cap;
 }
 
@@ -944,7 +966,9 @@ static int ensure_partition(ag_model *m)
     return AG_OK;
 }
 
-size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
+size_t ag_rollout_workspace_bytes(const ag_rollout_params *p) { return ag_rollout_workspace_bytes_for(nullptr, p); }
+
+size_t ag_rollout_workspace_bytes_for(const ag_model *m, const ag_rollout_params *p)
 {
     if (!p) return 0;
     // ag_rollout carves one layout per batch part and the number of parts is a model option ("rollout_streams", 1..4) the
@@ -959,7 +983,7 @@ size_t ag_rollout_workspace_bytes(const ag_rollout_params *p)
             float *a, *b, *d;
             int b0, nb;
             part_range(p->B, parts, k, &b0, &nb);
-            carve_rollout(c, p, nb, f, e, &a, &b, &d, AG_NHIS);
+            carve_rollout(c, p, nb, f, e, &a, &b, &d, AG_NHIS, table16(m));
         }
         need = c.off > need ? c.off : need;
     }
@@ -991,7 +1015,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
     struct Part { AgFwdArgs f{}; AgEdgeArgs e{}; float *state, *pp, *pm; int b0, B; } part[AG_MAX_PARTS];
     for (int k = 0; k < parts; ++k) {
         part_range(p->B, parts, k, &part[k].b0, &part[k].B);
-        carve_rollout(c, p, part[k].B, part[k].f, part[k].e, &part[k].state, &part[k].pp, &part[k].pm, H);
+        carve_rollout(c, p, part[k].B, part[k].f, part[k].e, &part[k].state, &part[k].pp, &part[k].pm, H, table16(m));
     }
     if (!c.ok()) return fail(AG_ERR_WS, "ag_rollout: workspace %zu < %zu bytes", workspace_bytes, c.off);
     if (parts > 1) {
@@ -1059,6 +1083,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
             setup_args(m, f, AG_MLP_WG_PER_CU * (m->n_cus - m->cu_split), p->n_steps);     // persistent node kernels: the HBM partition's CUs
             f.ws_blocks = m->cu_split;                                                     // edge encoder: one workgroup per CU of the MFMA partition
             run_node_encode(m, f, sR);
+            run_node_encode_fallback(m, f, sR);
             rc = encode(k);
         }
         for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
@@ -1071,6 +1096,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
                 if (ai < p->n_steps) {
                     { Timed tm(m, AG_K_EDGES, sR); ag_launch_build_edges(part[k].e, sR); }
                     if (!f.dedup) run_node_encode(m, f, sR);
+                    run_node_encode_fallback(m, f, sR);
                     rc = encode(k);
                 }
             }
@@ -1081,6 +1107,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
             { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
             if (ai == 1) setup_args(m, part[k].f, part_blocks, p->n_steps);
             if (ai == 1 || !part[k].f.dedup) run_node_encode(m, part[k].f, s);       // step-invariant when de-duplicated (see run_node_encode)
+            run_node_encode_fallback(m, part[k].f, s);
             run_edge_encode(m, part[k].f, s);
             if (ai == 1 && k == 0 && parts > 1 && m->stagger) {
                 // phase offset: the other parts start once part 0 has finished its first MFMA-bound encode stage, so

@@ -94,6 +94,13 @@ struct AgFwdArgs {
     float *h0c, *pnc, *hrc, *hsc;    // compact row-major tables [rows_c + 128][160]: particle_encode (= h of round 0), hoisted Pn, round 0's Hr / Hs
     int32_t *send_c;                 // (e_pad) edge_send mapped to compact rows: the first round's sender gathers
     int rows_c;                      // compact rows incl. padding; rows [rows_c, rows_c + 128) are dump rows of out-of-range lanes
+    // The compact tables are BOUNDED (r05): B * AG_DEDUP_REPS shared rows + a private budget of ~B N / 16 rows handed out through `priv_count`.
+    // A call whose inputs need more private rows raises `*ovf` (node_classify_kernel) and runs as if de-duplication were off: the compact
+    // encoder returns at once, the per-node encoder (launched every step behind a test of the flag) fills the full-size tables, and the first
+    // round's kernels read those (hr_full / hs_full, Pn and h from the packed tables).  Both paths give the same bits.
+    int *priv_count, *ovf;           // device words, zeroed with enc_count; ovf == NULL: no de-duplication in this call
+    int shared_rows;                 // = B * AG_DEDUP_REPS: first private row
+    const float *hr_full, *hs_full;  // round 0 only: the full-size tables the per-node encoder writes (read instead of hr / hs when *ovf)
     // per-launch views set by the sequencer (ag_api.hip: run_propagate)
     const int32_t *hr_row;           // segment reduce: row of Hr to read for node g (NULL: g) — node_row in round 0
     const float *pn_rows;            // node_update: Pn from compact rows pn_rows[node_row[g]] (NULL: packed table pn)
@@ -126,6 +133,11 @@ __device__ __forceinline__ float ag_q16_scale(int eb) { return ldexpf(1.0f / 327
 // A node has ~10 edges and every edge costs a dependent index -> row round trip, so FOUR edges are kept in flight per lane and
 // the sender indices of the next four are fetched one iteration ahead (the adds still run in ascending edge order: bit-identical to a
 // sequential loop).
+// round 0 of a de-duplicated call that overflowed the compact tables: the per-node encoder's full-size tables by node id
+__device__ __forceinline__ void ag_overflow_view(AgFwdArgs &a)
+{
+    if (a.ovf && a.hr_full && *a.ovf != 0) { a.hr = const_cast<float *>(a.hr_full); a.hs = const_cast<float *>(a.hs_full); a.hr_row = nullptr; }
+}
 #define AG_AGG_IN_FLIGHT 4
 #define AG_AGG_GROUP 20             // lanes per node
 #define AG_AGG_NODES_PER_WAVE 3
@@ -205,6 +217,7 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
 
 // kernel launchers (one translation unit each)
 void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
+void ag_launch_node_encode_fallback(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
 void ag_launch_send_remap(const AgFwdArgs &a, hipStream_t s);
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s);
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s);

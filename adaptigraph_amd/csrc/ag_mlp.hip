@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
     const int b = blockIdx.x * 4 + wave;
     if (b >= a.B) return;                                  // wave-uniform; the kernel has no workgroup-level synchronisation
     const int N = a.N, A = AG_ATTR, Pd = a.phys_dim, D = A + Pd + 3;
-    const int base = b * (N + AG_DEDUP_REPS);
+    const int base = b * AG_DEDUP_REPS;          // this sample's shared rows
     int nrep = 0;
     constexpr int kPre = 8;                                // 64-node slices whose inputs are fetched together (one memory round trip per 512 nodes)
     for (int s0 = 0; s0 < N; s0 += 64 * kPre) {
@@ -845,27 +845,30 @@ __global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
                 if (valid && match < 0 && eq) match = nrep;
                 if (lane == leader) {
                     const int slot = atomicAdd(a.enc_count, 1);
-                    a.enc_row[slot] = base + nrep;
-                    a.enc_src[slot] = (int)g;
+                    if (slot < a.rows_c) { a.enc_row[slot] = base + nrep; a.enc_src[slot] = (int)g; }
+                    else *a.ovf = 1;
                 }
                 ++nrep;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            const int row = match >= 0 ? base + match : base + AG_DEDUP_REPS + i;
-            if (valid) a.node_row[g] = row;
-            const unsigned long long priv = __ballot(valid && match < 0);       // rows of their own: one atomic per wave, not per lane
+            int row = base + match;
+            const unsigned long long priv = __ballot(valid && match < 0);       // rows of their own: one pair of atomics per wave, not per lane
             if (priv) {
                 const int first = __ffsll((long long)priv) - 1;
-                int slot0 = 0;
-                if (lane == first) slot0 = atomicAdd(a.enc_count, __popcll(priv));
+                int slot0 = 0, prow0 = 0;
+                if (lane == first) { slot0 = atomicAdd(a.enc_count, __popcll(priv)); prow0 = atomicAdd(a.priv_count, __popcll(priv)); }
                 slot0 = __shfl(slot0, first);
+                prow0 = __shfl(prow0, first);
                 if (valid && match < 0) {
-                    const int slot = slot0 + __popcll(priv & ((1ull << lane) - 1ull));
-                    a.enc_row[slot] = row;
-                    a.enc_src[slot] = (int)g;
+                    const int rank = __popcll(priv & ((1ull << lane) - 1ull));
+                    row = a.shared_rows + prow0 + rank;                      // private rows follow the B x AG_DEDUP_REPS shared ones
+                    const bool fits = row < a.rows_c && slot0 + rank < a.rows_c;
+                    if (!fits) { *a.ovf = 1; row = a.rows_c - 1; }           // budget exhausted: this call runs without de-duplication (every consumer tests ovf)
+                    else { a.enc_row[slot0 + rank] = row; a.enc_src[slot0 + rank] = (int)g; }
                 }
             }
+            if (valid) a.node_row[g] = row;
         }
     }
 }
@@ -874,7 +877,8 @@ __global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
 __global__ __launch_bounds__(256) void send_remap_kernel(AgFwdArgs a)
 {
     const int E = a.row_ptr[a.B * a.N];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) a.send_c[e] = a.node_row[a.edge_send[e]];
+    const bool ovf = *a.ovf != 0;                // the call overflowed the compact tables: round 0 gathers the full-size sender table by node id
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) a.send_c[e] = ovf ? a.edge_send[e] : a.node_row[a.edge_send[e]];
 }
 
 template <class Prec, bool DEDUP>
@@ -882,6 +886,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    // compact encoder: nothing to do when the call overflowed the compact tables; per-node encoder of a de-duplicated call (a.ovf set): only then
+    if (a.ovf && (*a.ovf != 0) == DEDUP) return;
     const int Mn = DEDUP ? *a.enc_count : a.B * a.N;      // rows to encode: the work list of node_classify_kernel, or every node
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;                // (de-duplicated: a handful of row tiles)
@@ -1626,6 +1632,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         const int nb = gridDim.x, bid = blockIdx.x, qq = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
         q.tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
+    const bool ovf = a.ovf && *a.ovf != 0;      // de-duplicated call that overflowed the compact tables: Pn / h come from the packed tables
+    const float *pn_rows = ovf ? nullptr : a.pn_rows, *h_rows = ovf ? nullptr : a.h_rows;
     f32x16 agg_next[AG_NT];      // (!FUSE) the agg rows of the row tile about to start
     bool have_next = false;
 #pragma unroll 1
@@ -1638,6 +1646,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 
         typename Prec::Act x, y;
         if constexpr (FUSE) {
+            AgFwdArgs ar = a;
+            ag_overflow_view(ar);
             const int ng = lane / AG_AGG_GROUP, c = lane - ng * AG_AGG_GROUP, f0 = ag_half_lane_feature(c);      // twenty lanes of one wave per node
             const int slot = wave * AG_AGG_NODES_PER_WAVE + ng;                                                      // 12 node slots per pass
 #pragma unroll 1
@@ -1649,8 +1659,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                         const int gn = tile * AG_ROWS_PER_BLOCK + grp * 32 + r;
                         float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
                         if (gn < Mn) {
-                            if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true>(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
-                            else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false>(a, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                            if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                            else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
                         }
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;
@@ -1678,8 +1688,8 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
         // Pn (+ h in round 0) come from the compact rows of the de-duplicated node encoder when it is on
-        const size_t crow = a.pn_rows ? (size_t)a.node_row[gc] * AG_FP + 4 * h : 0;
-        const ResidInit resid{a.pn_rows ? a.pn_rows + crow : a.pn + blk, a.h_rows ? a.h_rows + crow : a.h + blk, a.pn_rows != nullptr, a.h_rows != nullptr};
+        const size_t crow = pn_rows ? (size_t)a.node_row[gc] * AG_FP + 4 * h : 0;
+        const ResidInit resid{pn_rows ? pn_rows + crow : a.pn + blk, h_rows ? h_rows + crow : a.h + blk, pn_rows != nullptr, h_rows != nullptr};
         resid.prefetch();      // issued before the operand split of agg below, whose ~250 VALU instructions cover part of the latency
         if constexpr (!FUSE) {
 #pragma unroll
@@ -1960,6 +1970,13 @@ void ag_launch_node_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     else hipLaunchKernelGGL((node_encode_kernel<PrecF32, false>), grid, block, 0, s, w, a);
 }
 
+
+void ag_launch_node_encode_fallback(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
+{
+    const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3) hipLaunchKernelGGL((node_encode_kernel<PrecB3, false>), grid, block, 0, s, w, a);
+    else hipLaunchKernelGGL((node_encode_kernel<PrecF32, false>), grid, block, 0, s, w, a);
+}
 
 void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s)
 {

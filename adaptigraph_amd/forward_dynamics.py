@@ -39,7 +39,8 @@ def rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr_
         assert out.shape == (B, n_p, 3) and out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
     out_seq = out if out is not None else torch.zeros((B, n_p, 3), dtype=torch.float32, device=dev)
     state_final = torch.empty_like(state0, dtype=torch.float32) if return_state else None
-    ws = workspace(dev, L.ag_rollout_workspace_bytes(ctypes.byref(prm)))
+    h = model.handle(dev)
+    ws = workspace(dev, L.ag_rollout_workspace_bytes_for(h, ctypes.byref(prm)))      # exact for the model's current mode (q16 table: half the largest buffer)
     state0 = state0.contiguous().float()
     delta = delta.contiguous().float()
     attrs = attrs.contiguous().float()
@@ -49,7 +50,6 @@ def rollout(model, state0, delta, attrs, p_instance, phys, mask, tool_mask, thr_
     obj_u8 = _u8(obj_mask) if obj_mask is not None else None
     repeat = repeat.to(dev, torch.int32).contiguous()
     thr_sq = thr_sq.contiguous()
-    h = model.handle(dev)
     with torch.cuda.device(dev):
         rc = L.ag_rollout(h, ctypes.byref(prm), state0.data_ptr(), delta.data_ptr(), attrs.data_ptr(),
                           p_instance.data_ptr(), phys.data_ptr(), mask_u8.data_ptr(), tool_u8.data_ptr(),

@@ -171,8 +171,8 @@ class DynamicsPredictor(nn.Module):
         pred_pos = torch.empty((B, n_p, 3), dtype=torch.float32, device=dev)
         pred_motion = torch.empty((B, n_p, 3), dtype=torch.float32, device=dev)
         L = _lib.lib()
-        ws = workspace(dev, L.ag_forward_workspace_bytes(B, N, edges.e_cap))
         h = self.handle(dev)
+        ws = workspace(dev, L.ag_forward_workspace_bytes_for(h, B, N, edges.e_cap))
         with torch.cuda.device(dev):
             rc = L.ag_forward(h, state.data_ptr(), attrs.data_ptr(), action.data_ptr(), p_instance.data_ptr(),
                               n_inst, phys.data_ptr(), edges.row_ptr.data_ptr(), edges.edge_recv.data_ptr(),

@@ -48,6 +48,8 @@ def test_version_and_capacity_queries():
     assert fwd >= e_cap * 160 * 4 + 5 * 256 * 1001 * 160 * 4      # Eterm + five node tables
     prm = _lib.RolloutParams(256, 1001, 1000, 1, 10, 0, 1, 10, 0, 0.0)
     assert L.ag_rollout_workspace_bytes(ctypes.byref(prm)) > fwd
+    assert L.ag_rollout_workspace_bytes(ctypes.byref(prm)) <= 2.95e9               # bounded compact tables (r05; 3.55 GB until r04); 2.11 GB for a default-mode model
+    assert L.ag_rollout_workspace_bytes_for(None, ctypes.byref(prm)) == L.ag_rollout_workspace_bytes(ctypes.byref(prm))   # no model: any mode
     assert L.ag_edges_workspace_bytes(256, 1001, 10, 0, 1) >= 256 * 1001 * 11 * 4
 
 

@@ -371,6 +371,48 @@ def test_node_encoder_deduplication_is_bitwise_the_per_node_encoder(weights, pre
         assert torch.equal(on, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
 
 
+@pytest.mark.parametrize("mode,fuse", [("fast", 0), ("fast", 2), ("bf16x3", 0), ("f32", 0)])      # (the fused reduce exists in the default mode only)
+def test_dedup_overflow_falls_back_to_the_per_node_encoder(weights, mode, fuse):
+    """The compact tables of the de-duplicated node encoder are bounded (8 shared rows per sample + ~B N / 16 private rows, at least 1 024).
+    Inputs with more distinct rows — here a private row for every one of 3 x 6 001 nodes — raise a device flag and the call runs through the
+    per-node encoder (node_classify_kernel -> ovf; every consumer tests it): same bits as node_dedup 0, in one forward and through a rollout
+    whose later steps re-encode from the flag alone."""
+    n_obj, B = 6000, 3
+    g = synth.make_graph_inputs("rope", n_obj, B, seed=8, spacing=0.1)
+    rng = np.random.default_rng(5)
+    g["action"] = rng.normal(0, 0.05, g["action"].shape).astype(np.float32)
+    assert B * (n_obj + 1) > max(B * (n_obj + 1) // 16, 1024) + 8 * B
+    m = make_model(weights, "rope", prec=mode)
+    m.set_option("fuse_aggregate", fuse)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kwp = {"action": t(g["action"]), "rope_physics_param": t(g["phys"])}
+    thr = aggraph.threshold_sq(0.5, B, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    rep = torch.full((B,), 3, dtype=torch.int32, device=DEV)
+
+    def both():
+        pos, mot = m(*args, **kwp)
+        seq = rollout(m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]), thr, rep, 3,
+                      10, False, 1)
+        return pos, mot, seq
+
+    m.set_option("node_dedup", 0)
+    ref = both()
+    m.set_option("node_dedup", 2)
+    for _ in range(2):
+        got = both()
+        assert all(torch.isfinite(a).all() and torch.equal(a, b) for a, b in zip(got, ref))
+    assert m.take_status() == 0
+    # and the same model right afterwards on inputs that DO fit: the flag is per call
+    g2 = synth.make_graph_inputs("rope", 300, 2, seed=1, spacing=0.1)
+    csr2 = aggraph.build_edges(t(g2["state"][:, -1]), 0.5, t(g2["mask"]), t(g2["tool_mask"]), 10, False, "batch", max_tools=1)
+    a2 = (t(g2["state"]), t(g2["attrs"]), csr2, None, t(g2["p_instance"]))
+    k2 = {"action": t(g2["action"]), "rope_physics_param": t(g2["phys"])}
+    on = m(*a2, **k2)[1]
+    m.set_option("node_dedup", 0)
+    assert torch.equal(on, m(*a2, **k2)[1])
+
+
 def test_node_deduplication_through_the_masked_rollout(weights):
     """dynamics_masked (sys-id driver): per-sample initial clouds with padded object slots (attrs (0, 0): a second object class), the
     node encoder hoisted out of the step loop — de-duplicated, forced and off must agree bit for bit, and with the golden."""
@@ -789,6 +831,8 @@ def test_undersized_workspace_is_an_error_not_a_fault(weights, model):
     csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
     L = _lib.lib()
     need = L.ag_forward_workspace_bytes(2, 101, csr.e_cap)
+    hm = model.handle(torch.device(DEV))
+    assert L.ag_forward_workspace_bytes_for(hm, 2, 101, csr.e_cap) <= need
     ws = torch.empty(need // 2, dtype=torch.uint8, device=DEV)
     pos, mot = torch.full((2, 100, 3), 7.0, device=DEV), torch.full((2, 100, 3), 7.0, device=DEV)
     st, at, ac, pi, ph = (t(g[k]) for k in ("state", "attrs", "action", "p_instance", "phys"))
@@ -811,6 +855,41 @@ def test_undersized_workspace_is_an_error_not_a_fault(weights, model):
     # and the model is still usable afterwards (no state was left half-changed)
     _, again = model(st, at, csr, None, pi, action=ac, rope_physics_param=ph)
     assert torch.isfinite(again).all()
+
+
+def test_workspace_is_bounded_and_sized_for_the_models_mode(weights):
+    """ag_*_workspace_bytes_for(model, ...): exact for the model's current mode — the default mode's per-edge table is 16-bit rows, half the
+    largest buffer — and the compact tables of the node de-duplication are bounded.  Targets of VERDICT r04 item 3: rope-1k x 256 x 10 <= 2.9 GB,
+    the reference planner's 20 000 x 200 <= 40 GB.  A workspace sized for the default mode is refused (AG_ERR_WS) once the model needs fp32 rows."""
+    import ctypes
+    L = _lib.lib()
+    m = make_model(weights, prec="fast")
+    h = m.handle(torch.device(DEV))
+    c2 = _lib.RolloutParams(256, 1001, 1000, 1, 10, 0, 1, 10, 0, 0.0)
+    plan = _lib.RolloutParams(20000, 201, 200, 1, 10, 0, 1, 15, 0, 0.0)
+    any_c2, any_plan = L.ag_rollout_workspace_bytes(ctypes.byref(c2)), L.ag_rollout_workspace_bytes(ctypes.byref(plan))
+    fast_c2, fast_plan = L.ag_rollout_workspace_bytes_for(h, ctypes.byref(c2)), L.ag_rollout_workspace_bytes_for(h, ctypes.byref(plan))
+    print(f"rollout workspace: rope-1k x 256: {fast_c2 / 1e9:.2f} GB (any mode {any_c2 / 1e9:.2f}); 20 000 x 200: {fast_plan / 1e9:.1f} GB (any mode {any_plan / 1e9:.1f})")
+    assert fast_c2 <= 2.2e9 and fast_c2 <= any_c2 <= 2.95e9
+    assert fast_plan <= 40e9 and fast_plan <= any_plan <= 47e9
+    m.set_option("precision", 0)
+    assert L.ag_rollout_workspace_bytes_for(h, ctypes.byref(c2)) == any_c2
+    # sized for the 16-bit table, called in a mode that needs fp32 rows: an error code, nothing launched
+    g = synth.make_graph_inputs("rope", 100, 2, seed=1, spacing=0.1)
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    m.set_option("precision", 2)
+    small = L.ag_forward_workspace_bytes_for(h, 2, 101, csr.e_cap)
+    ws = torch.empty(small, dtype=torch.uint8, device=DEV)
+    pos, mot = torch.full((2, 100, 3), 7.0, device=DEV), torch.full((2, 100, 3), 7.0, device=DEV)
+    st, at, ac, pi, ph = (t(g[k]) for k in ("state", "attrs", "action", "p_instance", "phys"))
+    call = lambda: L.ag_forward(h, st.data_ptr(), at.data_ptr(), ac.data_ptr(), pi.data_ptr(), 1, ph.data_ptr(), csr.row_ptr.data_ptr(),
+                                csr.edge_recv.data_ptr(), csr.edge_send.data_ptr(), csr.e_cap, 2, 101, 100, pos.data_ptr(), mot.data_ptr(),
+                                ws.data_ptr(), ws.numel(), None)
+    assert call() == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(mot).all() and not bool((mot == 7.0).all())
+    m.set_option("precision", 1)
+    assert call() == -3 and b"workspace" in L.ag_last_error()
 
 
 @pytest.mark.parametrize("n_obj", [300, 1000])
