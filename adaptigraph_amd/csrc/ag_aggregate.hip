@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     ag_overflow_view(a);
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (a.agg_reverse) logical = nb - 1 - logical;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / AG_AGG_GROUP, c = lane - grp * AG_AGG_GROUP;
     if (grp >= AG_AGG_NODES_PER_WAVE) return;

@@ -70,6 +70,7 @@ struct AgFwdArgs {
     float clamp;
     unsigned long long *edge_counter;   // optional (profiling): += number of edges per edge_encode launch
     float *hr_out, *hs_out;   // where node_update writes the NEXT round's Hr/Hs (ping-pong with hr/hs)
+    int agg_reverse;          // segment reduce walks the nodes (and with them the per-edge table) from the END: see run_propagate
     int hs_q16, hs_out_q16;   // precision mode 2: the sender table `hs` read / the one written by this launch holds q16 rows (320 B, the Eterm format) instead
                               // of fp32 rows — the rounds after the first; round 0 gathers the node encoder's fp32 rows
     int precision;     // AG_PREC_F32 (exact fp32 MFMA) or AG_PREC_B3 (hi/lo bf16 split, 3 MFMAs per product)
