@@ -696,6 +696,25 @@ def test_strict_status_raises_in_the_call_that_caused_it(weights, monkeypatch):
         assert any("non-finite" in str(x.message) for x in rec)
 
 
+@pytest.mark.parametrize("split", [32, 96, 224])
+def test_cu_partitioned_rollout_is_bitwise_the_shared_chip_rollout(weights, split):
+    """ag_set_option("cu_split", X): the edge encoder on X / 8 CUs of every XCD, everything else on the other CUs, two CU-masked queues with
+    the batch parts pipelined through them (measured slower than sharing the chip, off by default).  Same kernels, same
+    per-row arithmetic: bit-identical results, repeatable, and the option switches back cleanly."""
+    state, act = synth.make_mpc_inputs("rope", 300, 24, seed=6, len_lo=3, len_hi=5.9, spacing=0.1)
+    m = make_model(weights, "rope", prec="fast")
+    ref = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+    m.set_option("cu_split", split)
+    for _ in range(3):
+        assert torch.equal(dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"], ref)
+    m.set_option("rollout_streams", 3)
+    assert torch.equal(dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"], ref)
+    m.set_option("cu_split", 0)
+    assert torch.equal(dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"], ref) and m.take_status() == 0
+    with pytest.raises(RuntimeError):
+        m.set_option("cu_split", 100)           # not a multiple of 8
+
+
 def test_rollout_is_hip_graph_capturable(weights):
     """ag_rollout never synchronises the host and joins its auxiliary streams on every path, so a caller may capture it in a HIP graph
     (torch.cuda.graphs): the replayed rollout equals the enqueued one bit for bit, twice (replay is not faster, the point is
