@@ -238,6 +238,8 @@ struct ag_model {
     int edge_products = 2;      // precision mode 2: 2 = fp16 edge stack (split-fp16 weights x fp16 activations + e5m2 residual bytes: PrecH3),
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
+    int node_ws = 1;            // split-bf16 node_update of the rounds before the last on the weight-stationary kernel (default; env AG_NODE_WS /
+                                // "node_stationary" 0 = the streaming kernel); bit-identical
     int edge_ws = 1;            // fp16 edge stack (PrecH3) on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
     int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
@@ -427,6 +429,7 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
     a.max_blocks = max_blocks;     // per call, not per model: a model shared by two callers is not mutated
     a.edge_products = m->h2_ok ? m->edge_products : 3;      // a checkpoint with edge-stack weights beyond fp16's range keeps the split-bf16 edge stack
     a.edge_ws = m->edge_ws;
+    a.node_ws = m->node_ws;
     a.dedup = m->node_dedup && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&
               (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
     a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr; a.hr_full = nullptr; a.hs_full = nullptr;
@@ -534,6 +537,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
+    if (const char *v = getenv("AG_NODE_WS")) m->node_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
@@ -783,6 +787,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
         m->edge_products = value;
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
+    else if (!strcmp(name, "node_stationary")) m->node_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "cu_split")) {
         if (value != 0 && (value < 8 || value > m->n_cus - 8 || (value & 7)))

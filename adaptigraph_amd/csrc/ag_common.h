@@ -83,6 +83,7 @@ struct AgFwdArgs {
     int edge_products; // precision mode 2 only: 2 = fp16 edge stack with residual bytes (PrecH3, default), 3 = split-bf16 like mode 1
     int ws_blocks;     // workgroups of the weight-stationary edge encoder for this launch
     int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
+    int node_ws;       // split-bf16 node_update of the rounds before the last on the weight-stationary kernel (ag_mlp.hip: node_update_nws_kernel)
     // ---- node-encoder de-duplication.  The node encoder sees [attrs | phys | action] only (positions do not enter:
     // model.py:168-173 is skipped for state_dim = 0), and every rollout driver of the reference gives all object particles of a sample
     // the same row (forward_dynamics.py:83-123: attrs (1,0), the sample's physics parameter, zero action), so particle_encode, the hoisted

@@ -1747,6 +1747,247 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
     }
 }
 
+// =====================================================================================================================
+// Weight-STATIONARY node update of the rounds before the last (precision modes 1 / 2; ag_set_option("node_stationary", 1)).
+//
+// The streaming node_update_kernel re-reads its 15 weight chunks (300 KB) from L2 for every 128 rows: 0.60 GB per launch at C2 beside 0.74 GB
+// of tables, and the timing-only build without those copies is 17 % shorter (profiles/r05_node_update_ablation.txt).  Here ONE 256-thread
+// workgroup per CU (one wave per SIMD, 496 registers per lane) keeps all 15 (layer, out-tile) units' split-bf16 A operands in registers for
+// the whole launch — wave w owns out-tile w of each of the three layers, the fifth tiles go one each to waves 0, 1, 2 — and 32-row blocks
+// flow through as a two-stage pipeline with ONE barrier per block:
+//     phase p:   first layer (h' = relu(W_pp[:, F:] agg + Pn + h)) of block p        input set X[p & 1]  -> h' to HBM + output set Y[p & 1]
+//                Hr / Hs layers of block p - 1 (one pass over the set for both)        input set Y[(p - 1) & 1]
+//                agg rows of block p + 1: loaded at the top of the phase, split into bf16 hi / lo and written to X[(p + 1) & 1] at its end
+// A set is the 160 x 32 activation block in the B-operand layout of the next layer (lane (j, h) writes the bytes lane (j, h) of a consumer
+// reads): [10 k16-steps][hi | lo][64 lanes][8 bf16] = 20 KB.  Every accumulator sees its k16-steps in ascending order with the products in
+// the streaming kernel's order (lo.hi, hi.lo, hi.hi) and is initialised the same way, so the results equal node_update_kernel bit for bit.
+// =====================================================================================================================
+#define AG_NWS_SET 20480
+struct NwsUnit { bf16x8 hi[10], lo[10]; };
+
+// ACC: the unit lives in the accumulation-register half of the file (the matrix instructions read their A operand from there directly): a
+// wave's first three units; the fourth (waves 0-2) sits in architectural registers.  Left to the compiler (builtin MFMAs), the 320 weight
+// registers end up wherever it likes, with ~1 750 accumulation-register moves per block and spills.
+template <bool ACC>
+__device__ __forceinline__ void nws_load_unit(NwsUnit &W, const float4 *chunk, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        W.hi[u] = *reinterpret_cast<const bf16x8 *>(chunk + (2 * u) * 64 + lane);
+        W.lo[u] = *reinterpret_cast<const bf16x8 *>(chunk + (2 * u + 1) * 64 + lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {      // opaque (after ALL the loads): must stay in registers, cannot be re-loaded in the loop
+        if constexpr (ACC) asm volatile("" : "+a"(W.hi[u]), "+a"(W.lo[u]));
+        else asm volatile("" : "+v"(W.hi[u]), "+v"(W.lo[u]));
+    }
+}
+// one k16-step of one unit: acc += lo.xh + hi.xl + hi.xh in the streaming kernel's order; inline asm so that the A operands are read where the
+// unit lives.  (s_nop 1: two wait states between a VALU / LDS-load written operand and the matrix instruction that reads it.)
+template <bool ACC>
+__device__ __forceinline__ void nws_mfma3(f32x16 &acc, const bf16x8 &wh, const bf16x8 &wl, const bf16x8 &xh, const bf16x8 &xl)
+{
+    if constexpr (ACC)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0"
+                     : "+v"(acc) : "a"(wl), "a"(wh), "v"(xh), "v"(xl));
+    else
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0"
+                     : "+v"(acc) : "v"(wl), "v"(wh), "v"(xh), "v"(xl));
+}
+// results of asm MFMAs are not interlocked against the compiler's VALU readers: 8 passes + 4 states, with margin
+__device__ __forceinline__ void nws_settle(f32x16 &a) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a)); }
+// up to three units over ONE input set (la: LDS byte address of this lane's 16 bytes of k16-step 0): the operand pair of step u + 2 is read
+// while step u's matrix instructions run (inline-asm reads with counted waits: left to the compiler every step waited a full LDS round trip)
+template <int NU, bool ACC0, bool ACC1, bool ACC2>
+__device__ __forceinline__ void nws_layer(f32x16 (&acc)[NU], const NwsUnit &W0, const NwsUnit &W1, const NwsUnit &W2, unsigned la)
+{
+    bf16x8 xq[3][2];
+    lds_read16<0>(xq[0][0], la);
+    lds_read16<1024>(xq[0][1], la);
+    lds_read16<2048>(xq[1][0], la);
+    lds_read16<3072>(xq[1][1], la);
+    static_for<0, 10>([&](auto UU) {
+        constexpr int u = decltype(UU)::value;
+        if constexpr (u + 2 < 10) {
+            lds_read16<(2 * (u + 2)) * 1024>(xq[(u + 2) % 3][0], la);
+            lds_read16<(2 * (u + 2) + 1) * 1024>(xq[(u + 2) % 3][1], la);
+        }
+        constexpr int ahead = (9 - u) < 2 ? (9 - u) : 2;
+        lds_wait_pair<2 * ahead>(xq[u % 3][0], xq[u % 3][1]);
+        nws_mfma3<ACC0>(acc[0], W0.hi[u], W0.lo[u], xq[u % 3][0], xq[u % 3][1]);
+        if constexpr (NU >= 2) nws_mfma3<ACC1>(acc[1], W1.hi[u], W1.lo[u], xq[u % 3][0], xq[u % 3][1]);
+        if constexpr (NU >= 3) nws_mfma3<ACC2>(acc[NU - 1], W2.hi[u], W2.lo[u], xq[u % 3][0], xq[u % 3][1]);
+    });
+#pragma unroll
+    for (int k = 0; k < NU; ++k) nws_settle(acc[k]);
+}
+// k16-step `step` of a set from eight fp32 values in accumulator order (PrecB3::set_half's conversion)
+__device__ __forceinline__ void nws_write_half(unsigned char *set_lane, int step, const float (&x)[8])
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 H, L;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned hp = cvt_pk_bf16(x[2 * w], x[2 * w + 1]);
+        const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
+        H[w] = hp;
+        L[w] = cvt_pk_bf16(x[2 * w] - h0, x[2 * w + 1] - h1);
+    }
+    *reinterpret_cast<u32x4 *>(set_lane + (2 * step) * 1024) = H;
+    *reinterpret_cast<u32x4 *>(set_lane + (2 * step + 1) * 1024) = L;
+}
+
+template <int WAVE, bool HSQ>
+__device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a, unsigned char *sX, unsigned char *sY)
+{
+    constexpr int N1 = WAVE == 3 ? 2 : 1, N2 = WAVE == 1 ? 2 : 1, N3 = WAVE == 2 ? 2 : 1;      // the fifth out-tiles: one each to waves 3, 1, 2
+    constexpr int N23 = N2 + N3;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int Mn = a.B * a.N;
+    const int nblk = (Mn + 31) / 32;
+    const int n_i = ((int)blockIdx.x < nblk) ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const bool ovf = a.ovf && *a.ovf != 0;
+    const float *pn_rows = ovf ? nullptr : a.pn_rows, *h_rows = ovf ? nullptr : a.h_rows;
+    NwsUnit U1[N1], U2[N2], U3[N3];
+    const float4 *ws = w.node_mid_b3;
+    // placement: a wave's units U1[0], U2[0], U3[0] sit in accumulation registers (240), its fifth-tile unit (waves 0-2) in architectural ones
+    nws_load_unit<true>(U1[0], ws + (size_t)(0 + WAVE) * AG_CHUNK_F4, lane);
+    nws_load_unit<true>(U2[0], ws + (size_t)(5 + WAVE) * AG_CHUNK_F4, lane);
+    nws_load_unit<true>(U3[0], ws + (size_t)(10 + WAVE) * AG_CHUNK_F4, lane);
+    if constexpr (N1 == 2) nws_load_unit<false>(U1[1], ws + (size_t)(0 + 4) * AG_CHUNK_F4, lane);
+    if constexpr (N2 == 2) nws_load_unit<false>(U2[1], ws + (size_t)(5 + 4) * AG_CHUNK_F4, lane);
+    if constexpr (N3 == 2) nws_load_unit<false>(U3[1], ws + (size_t)(10 + 4) * AG_CHUNK_F4, lane);
+    const int t1[2] = {WAVE, 4}, t2[2] = {WAVE, 4}, t3[2] = {WAVE, 4};
+    auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    // input staging: this wave converts k16-steps WAVE, WAVE + 4, WAVE + 8 (< 10) of the next block's agg rows
+    constexpr int NS = WAVE < 2 ? 3 : 2;
+    float4 raw[NS][2];
+    auto stage_load = [&](int i) {
+        const size_t g = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
+        const float *row = a.agg + g * AG_FP + 4 * h;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int u = WAVE + 4 * k;
+            raw[k][0] = *reinterpret_cast<const float4 *>(row + 16 * u);
+            raw[k][1] = *reinterpret_cast<const float4 *>(row + 16 * u + 8);
+        }
+    };
+    auto stage_write = [&](unsigned char *set) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float x[8] = {raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w};
+            nws_write_half(set + lane * 16, WAVE + 4 * k, x);
+        }
+    };
+    // residual Pn + h of this wave's first-layer tiles, loaded one phase ahead; the compact-row index of a block (node de-duplication) one
+    // phase earlier still, so that no load in the loop body depends on another load of the same phase
+    f32x16 rh[N1];
+    const float *pn_ptr = nullptr;
+    int idx_raw = 0;                                     // node_row of block i + 1, in flight during a phase
+    const int32_t *idx_tab = pn_rows ? a.node_row : a.row_ptr;      // (without de-duplication: any valid table, the value is not used)
+    size_t crow_cur = 0;                                 // compact-row offset of the block whose residual is loaded next (a VALUE)
+    auto idx_load = [&](int i) {
+        const size_t g = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
+        idx_raw = idx_tab[g < (size_t)Mn ? g : 0];       // (unconditional: a `cond ? load : 0` costs a conservative wait at the top of the loop body)
+    };
+    auto resid_load = [&](int i) {
+        const int blk = i < n_i ? gblock(i) : 0;
+        const size_t pk = (size_t)blk * AG_PACK_BLOCK + h * 128 + j * 4;
+        pn_ptr = pn_rows ? pn_rows + crow_cur : a.pn + pk;      // Pn (two L2-hot compact rows per sample in the reference's rollouts) is loaded where it is
+#pragma unroll                                                 // added: 16 registers per tile less in flight through the phase
+        for (int k = 0; k < N1; ++k) ResidInit::load_tile(h_rows ? h_rows + crow_cur : a.h + pk, h_rows != nullptr, t1[k], rh[k]);
+    };
+    // Nothing that is still in flight is carried over the loop's back edge (the compiler's wait-count analysis answers a loop-carried pending load
+    // with a full vmcnt(0) at the top of the body, previous phase's stores included): a phase issues the next block's loads at its top and turns
+    // them into VALUES at its end — the staged operand set in LDS and the first layer's accumulator initialisation Pn + h in `acc1`.
+    f32x16 acc1[N1];
+    auto resid_to_acc = [&]() {
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            f32x16 rp;      // (loaded HERE: hoisted in front of the Hr / Hs pass it costs 16 registers per tile through that pass — spills, 0.171 ms)
+            ResidInit::load_tile(pn_ptr, pn_rows != nullptr, t1[k], rp);
+            ResidInit::zero_pad(pn_rows != nullptr, t1[k], rp);
+            ResidInit::zero_pad(h_rows != nullptr, t1[k], rh[k]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[k][r] = rp[r] + rh[k][r];
+        }
+    };
+    idx_load(0);
+    crow_cur = (size_t)idx_raw * AG_FP + 4 * h;
+    stage_load(0);
+    resid_load(0);
+    idx_load(1);
+    stage_write(sX);
+    resid_to_acc();
+    crow_cur = (size_t)idx_raw * AG_FP + 4 * h;          // block 1
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p <= n_i; ++p) {
+        unsigned char *X = sX + (p & 1) * AG_NWS_SET, *Xn = sX + ((p + 1) & 1) * AG_NWS_SET;
+        unsigned char *Y = sY + (p & 1) * AG_NWS_SET, *Yp = sY + ((p + 1) & 1) * AG_NWS_SET;
+        if (p + 1 < n_i) { stage_load(p + 1); resid_load(p + 1); idx_load(p + 2); }
+        if (p < n_i) {                                   // first layer of block p
+            const int blk = gblock(p);
+            nws_layer<N1, true, false, false>(acc1, U1[0], U1[N1 - 1], U1[N1 - 1], lds_addr_of(X) + lane * 16);
+            const PackStoreEpi store{a.h + (size_t)blk * AG_PACK_BLOCK + h * 128 + j * 4};
+#pragma unroll
+            for (int k = 0; k < N1; ++k) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[k][r] = relu1(acc1[k][r]);
+                store(t1[k], acc1[k]);
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const float x[8] = {acc1[k][8 * sh], acc1[k][8 * sh + 1], acc1[k][8 * sh + 2], acc1[k][8 * sh + 3],
+                                        acc1[k][8 * sh + 4], acc1[k][8 * sh + 5], acc1[k][8 * sh + 6], acc1[k][8 * sh + 7]};
+                    nws_write_half(Y + lane * 16, 2 * t1[k] + sh, x);
+                }
+            }
+        }
+        // Hr / Hs of block p - 1: one pass over the set for both layers' units.  The next block's loads are turned into values BETWEEN this pass and
+        // its stores: the compiler's counted waits then see only the first layer's (by now old) stores behind the loads, not fresh ones.
+        f32x16 acc[N23];
+        const size_t g = (size_t)gblock(p >= 1 ? p - 1 : 0) * 32 + j;
+        if (p >= 1) {
+#pragma unroll
+            for (int k = 0; k < N23; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+            const unsigned la = lds_addr_of(Yp) + lane * 16;
+            // unit order in acc: U2[0], (U2[1]), U3[0], (U3[1])
+            if constexpr (N2 == 2) nws_layer<3, true, false, true>(acc, U2[0], U2[1], U3[0], la);
+            else if constexpr (N3 == 2) nws_layer<3, true, true, false>(acc, U2[0], U3[0], U3[1], la);
+            else nws_layer<2, true, true, false>(acc, U2[0], U3[0], U3[0], la);
+        }
+        if (p + 1 < n_i) { stage_write(Xn); resid_to_acc(); crow_cur = (size_t)idx_raw * AG_FP + 4 * h; }
+        if (p >= 1) {
+            const RowStoreEpi sr{a.hr_out + g * AG_FP + 4 * h};
+#pragma unroll
+            for (int k = 0; k < N2; ++k) sr(t2[k], acc[k]);
+            if constexpr (HSQ) {
+                const RowStoreQ16Epi sq{reinterpret_cast<unsigned char *>(a.hs_out) + g * (2 * AG_FP), h, a.status};
+#pragma unroll
+                for (int k = 0; k < N3; ++k) sq(t3[k], acc[N2 + k]);
+            } else {
+                const RowStoreEpi ss{a.hs_out + g * AG_FP + 4 * h};
+#pragma unroll
+                for (int k = 0; k < N3; ++k) ss(t3[k], acc[N2 + k]);
+            }
+        }
+        ws_round_barrier();      // LDS side only: __syncthreads() would also drain this phase's table stores (vmcnt(0)) with the whole CU waiting
+    }
+}
+
+template <bool HSQ>
+__global__ __launch_bounds__(256, 1) void node_update_nws_kernel(AgWeights w, AgFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sX[2 * AG_NWS_SET], sY[2 * AG_NWS_SET];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) nws_wave<0, HSQ>(w, a, sX, sY);
+    else if (wave == 1) nws_wave<1, HSQ>(w, a, sX, sY);
+    else if (wave == 2) nws_wave<2, HSQ>(w, a, sX, sY);
+    else nws_wave<3, HSQ>(w, a, sX, sY);
+}
+
 // =====================================================================================================
 // Training path: the dense stacks of DynamicsPredictor.forward and their backward on the
 // same fused-layer machinery, in either arithmetic: exact fp32 MFMA (PrecF32) or split-bf16 (PrecB3: 2^-17 relative operand
@@ -2001,6 +2242,13 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hipStream_t s)
 {
     const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
+    if (a.precision == AG_PREC_B3 && !last && a.node_ws && !a.fuse_agg) {      // weight-stationary kernel: one workgroup per CU
+        const int cus = a.max_blocks / AG_MLP_WG_PER_CU > 0 ? a.max_blocks / AG_MLP_WG_PER_CU : 1, nblk = (a.B * a.N + 31) / 32;
+        const dim3 g2(nblk < cus ? nblk : cus);
+        if (a.hs_out_q16) hipLaunchKernelGGL(node_update_nws_kernel<true>, g2, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL(node_update_nws_kernel<false>, g2, dim3(256), 0, s, w, a);
+        return;
+    }
     if (a.precision == AG_PREC_B3) {
         if (a.fuse_agg == 2 && a.eterm_half) {      // cooperative LDS-staged reduce inside the kernel (no aggregate launch, no agg table)
             if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, true>), grid, block, 0, s, w, a);

@@ -67,6 +67,9 @@ int ag_model_destroy(ag_model *m);
  *                            keep 3), 3 = split-bf16 like precision 1
  *   "edge_stationary"  0/1   with edge_products 2: 1 = weight-stationary kernel (default: weights in registers, activations handed from wave
  *                            to wave through LDS), 0 = streaming kernel (weights through LDS per 128 edges); bit-identical results
+ *   "node_stationary"  0/1   precision 1 / 2, rounds before the last: 1 = weight-stationary node update (default: one workgroup per CU keeps the three
+ *                            layers' split-bf16 weights in registers, 32-row blocks pipelined through LDS), 0 = streaming kernel (weights through
+ *                            LDS per 128 rows); bit-identical results
  *   "node_dedup"       0/1/2 particle_encoder / hoisted Pn / the first round's Hr, Hs computed once per DISTINCT [attrs | phys | action] row of a sample
  *                            (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout call: 1 (default) =
  *                            where it pays (>= 32 768 node-rows x steps per call), 2 = always, 0 = never (once per node and model step).

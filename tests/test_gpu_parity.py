@@ -302,6 +302,35 @@ def test_weight_stationary_edge_encoder_is_bitwise_the_streaming_kernel(weights,
 
 
 
+@pytest.mark.parametrize("mode", ["fast", "bf16x3"])
+@pytest.mark.parametrize("material,n_obj,batch,dedup", [("rope", 700, 5, 2), ("rope", 40, 1, 2), ("granular", 2000, 2, 0), ("cloth", 1024, 3, 2), ("rope", 1000, 40, 1)])
+def test_weight_stationary_node_update_is_bitwise_the_streaming_kernel(weights, mode, material, n_obj, batch, dedup):
+    """The rounds before the last run their node update on the weight-stationary kernel by default (r05: one 256-thread workgroup per CU keeps the
+    fifteen (layer, out-tile) units' split-bf16 weights in registers, 32-row blocks flow through LDS as a two-stage pipeline, inline-asm MFMAs);
+    ag_set_option("node_stationary", 0) selects the streaming kernel.  Every accumulator keeps its order: bit-identical, repeatable — with a partial
+    last 32-row block, fewer blocks than workgroups, compact (de-duplicated) and packed residual tables, and through a two-stream rollout."""
+    m = make_model(weights, material, prec=mode)
+    m.set_option("node_dedup", dedup)
+    g = synth.make_graph_inputs(material, n_obj, batch, seed=19, **(dict(spacing=0.1) if material == "rope" else {}))
+    mm = synth.MATERIALS[material]
+    csr = aggraph.build_edges(t(g["state"][:, -1]), mm["radius"], t(g["mask"]), t(g["tool_mask"]), mm["topk"], mm["connect_tools_all"],
+                              "batch", max_tools=g["n_tools"])
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kw2 = {"action": t(g["action"]), material + "_physics_param": t(g["phys"])}
+    m.set_option("node_stationary", 0)
+    pos0, ref = m(*args, **kw2)
+    m.set_option("node_stationary", 1)
+    for _ in range(5):
+        pos1, out = m(*args, **kw2)
+        assert torch.isfinite(out).all() and torch.equal(ref, out) and torch.equal(pos0, pos1)
+    if material == "rope" and n_obj == 1000:
+        state, act = synth.make_mpc_inputs("rope", 300, 24, seed=6, len_lo=3, len_hi=5.9, spacing=0.1)
+        on = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+        m.set_option("node_stationary", 0)
+        assert torch.equal(on, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
+    assert m.take_status() == 0
+
+
 def test_fused_segment_reduce_equals_the_separate_kernel(weights):
     """ag_set_option("fuse_aggregate", 2): the round's segment reduce inside node_update (no `agg` table, no aggregate launch) adds
     every node's messages in the same order as aggregate_half_kernel, so outputs are bit-identical to the default path — on a
