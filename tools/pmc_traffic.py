@@ -8,14 +8,15 @@ only quotes it while those sources are the ones running.
 Corrections per MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of wide streaming reads,
 so bytes = 2 x FETCH_SIZE(KB) x 1024 + WRITE_SIZE(KB) x 1024, per dispatch; dispatches are full-batch launches
 (--streams 1)."""
-import argparse, json, os, sqlite3, subprocess, sys, tempfile
+import argparse, json, os, re, sqlite3, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (csrc_sha)
 
 RUNS = [("rope", 256, 10, "fast"), ("rope", 256, 10, "f32"), ("granular", 128, 10, "fast"), ("cloth", 64, 20, "fast")]
 KERNELS = {"edge_encode": ("edge_encode_kernel", "edge_encode_nb_kernel", "edge_encode_ws_kernel"), "aggregate": ("aggregate_half_kernel", "aggregate_kernel"),
-           "node_update": ("node_update_kernel",), "node_encode": ("node_encode_kernel",)}
+           "node_update": ("node_update_kernel", "node_update_nws_kernel"), "node_update_stationary": ("node_update_nws_kernel",),
+           "node_update_last": ("node_update_kernel",), "node_encode": ("node_encode_kernel",)}
 
 
 def one_pass(counter, mat, batch, T, prec, tmp):
@@ -29,7 +30,14 @@ def one_pass(counter, mat, batch, T, prec, tmp):
     for kn, v in sqlite3.connect(db).execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
         a = acc.setdefault(kn, [0.0, 0])
         a[0] += v; a[1] += 1
-    return {k: s / n for k, (s, n) in acc.items()}
+    return acc          # kernel name -> [sum over dispatches, dispatches]
+
+
+def per_dispatch(acc, names):
+    """Average over all DISPATCHES of the kernels whose name contains one of `names` (a class with two kernels is weighted by launches)."""
+    hit = [v for k, v in acc.items() if any(re.search(r"\b" + n + r"\b", k) for n in names)]
+    n = sum(c for _, c in hit)
+    return sum(s for s, _ in hit) / n if n else None
 
 
 def main():
@@ -42,8 +50,9 @@ def main():
             f = one_pass("FETCH_SIZE", mat, batch, T, prec, tmp)
             w = one_pass("WRITE_SIZE", mat, batch, T, prec, tmp)
             for key, names in KERNELS.items():
-                fk = sum(v for k, v in f.items() if any(n in k for n in names)) / max(1, sum(1 for k in f if any(n in k for n in names)))
-                wk = sum(v for k, v in w.items() if any(n in k for n in names)) / max(1, sum(1 for k in w if any(n in k for n in names)))
+                fk, wk = per_dispatch(f, names), per_dispatch(w, names)
+                if fk is None:
+                    continue
                 entries[f"{mat}/{batch}/{prec}/{key}"] = (2 * fk + wk) * 1024
                 raw[f"{mat}/{batch}/{prec}/{key}"] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk}
     rec = {"csrc_sha256": bench.csrc_sha(), "entries": entries, "raw_kb_per_dispatch": raw,
