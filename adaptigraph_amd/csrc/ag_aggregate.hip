@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 #pragma unroll
         for (int i = 0; i < kFly; ++i)
             if (s[i] >= 0) {
-                t[i] = *reinterpret_cast<const float4 *>(a.eterm + (size_t)(e + i) * AG_FP + 4 * c);
+                t[i] = ag_ld_nt(reinterpret_cast<const float4 *>(a.eterm + (size_t)(e + i) * AG_FP + 4 * c));
                 u[i] = *reinterpret_cast<const float4 *>(a.hs + (size_t)s[i] * AG_FP + 4 * c);
             }
 #pragma unroll
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 #pragma unroll
         for (int i = 0; i < kFly; ++i) s[i] = sn[i];
     }
-    *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + 4 * c) = acc;
+    ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + 4 * c), acc);
     if (a.status && !isfinite((acc.x + acc.y) + (acc.z + acc.w))) atomicOr(a.status, 1);
 }
 
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
     float4 acc0, acc1;
     ag_reduce_node_q16<AG_AGG_IN_FLIGHT, HSQ>(a, g, c, grp * AG_AGG_GROUP, acc0, acc1);      // (6 or 8 edges in flight with the q16 sender table: no change)
     const int f0 = ag_half_lane_feature(c);
-    *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0) = acc0;
-    *reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8) = acc1;
+    ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0), acc0);
+    ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8), acc1);
 }
 
 }  // namespace

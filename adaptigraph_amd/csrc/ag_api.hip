@@ -487,6 +487,7 @@ void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
         // holds the END of what that pass touched: alternate the direction — the edge encoder writes the table front to back, so round 0
         // starts at the back, round 1 at the front, ... — and every pass begins where the last one ended.  Measured: segment reduce 0.2472 ->
         // 0.2452 ms per launch at C2 (-0.8 %: the cache holds a quarter of one pass, and the reduce is not latency-bound enough to care); same bits.
+        // (With the non-temporal hints on the table's loads, ag_common.h, the direction no longer matters: never / always / alternating within 0.5 %.)
         r.agg_reverse = (p & 1) == 0 ? 1 : 0;
         r.hs_q16 = (a.eterm_half && p > 0) ? 1 : 0;                     // rounds after the first gather the q16 rows the previous node_update wrote
         r.hs_out_q16 = (a.eterm_half && p + 1 < a.pstep) ? 1 : 0;

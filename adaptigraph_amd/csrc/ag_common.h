@@ -149,6 +149,17 @@ __device__ __forceinline__ int ag_half_lane_feature(int c) { return 32 * (c >> 2
 // two, half the gathered bytes.  Sender terms are independent per edge, so their 16-bit rounding averages out over a receiver's edges (float64
 // emulation on the random sweep's cases: worst deviation 8.3e-6 -> 8.5e-6); the receiver term Hr, common to all edges of a node, stays fp32
 // (as q16 it adds coherently: 1.5e-5).
+// Non-temporal hints (the `nt` bit of global_load / global_store) on streams that are touched ONCE per launch and are far larger than L2 + Infinity
+// Cache: the per-edge table in the segment reduce, the reduce's `agg` store, `h` in node_update (loaded once, stored once per round).  They change no
+// value, only what the caches keep: measured at C2 (r05, profiles/r05_nt_hints.txt) the reduce goes 0.245 -> 0.207 ms per launch (4.6 -> 5.4 TB/s),
+// +4 % graph-steps/s.  NOT everything read once gains: `nt` on node_update's `agg` loads (rows the reduce has just written) costs that kernel 24 %,
+// on the edge encoder's per-edge table stores 4 %, on the Hr / Hs stores 1-2 %; the sc0 / sc1 scope bits make no difference on any of them.
+typedef int ag_i32x4 __attribute__((ext_vector_type(4)));
+typedef float ag_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ag_ld_nt(const int4 *p) { const ag_i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_i32x4 *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { const ag_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_f32x4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin_nontemporal_store(ag_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ag_f32x4 *>(p)); }
+
 template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
 __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
 {
@@ -176,7 +187,7 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                t[i] = et[(size_t)(e + i) * (AG_FP / 8)];
+                t[i] = ag_ld_nt(&et[(size_t)(e + i) * (AG_FP / 8)]);
                 if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
                 else {
                     u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);

@@ -206,7 +206,7 @@ __device__ __forceinline__ void q16_store_half(unsigned char *row, int ti, int h
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     unsigned char *p = row + 64 * ti + 32 * h + 16 * s;
-    if (ti == 4 && s == 1) *reinterpret_cast<u32x2 *>(p) = u32x2{w[0], w[1]};
+    if (ti == 4 && s == 1) *reinterpret_cast<u32x2 *>(p) = u32x2{w[0], w[1]};       // (plain stores: `nt` here costs the edge encoder 4 %, ag_common.h)
     else *reinterpret_cast<u32x4 *>(p) = u32x4{w[0], w[1], w[2], w[3]};
 }
 __device__ __forceinline__ void q16_store_exp(unsigned char *row, int ti, int h, int eb) { row[ag_q16_exp_byte_offset(ti, h)] = (unsigned char)eb; }
@@ -243,7 +243,7 @@ struct PackStoreEpi {       // same for the fragment-image tables (h, Pn); blk_l
     {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(blk_lane + ((ti * 4 + q) * 2) * 128) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            ag_st_nt(reinterpret_cast<float4 *>(blk_lane + ((ti * 4 + q) * 2) * 128), make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
     }
 };
 
@@ -269,6 +269,7 @@ struct ResidInit {  // accumulator := Pn + h, i.e. W_pp[:, :F].enc + b_pp + resi
     bool pn_rowmajor, h_rowmajor;
     mutable f32x16 hraw[AG_NT];       // h of all five out-tiles, issued at the row tile's top
     mutable f32x16 pnext;             // Pn of the NEXT out-tile
+    template <bool NT = false>
     __device__ __forceinline__ static void load_tile(const float *p, bool rowmajor, int ti, f32x16 &d)
     {
 #pragma unroll
@@ -276,7 +277,8 @@ struct ResidInit {  // accumulator := Pn + h, i.e. W_pp[:, :F].enc + b_pp + resi
             // ONE unconditional 16-byte load per quad (address by select; a load under `if (rowmajor)` is split into predicated dword loads)
             const int off = ((ti * 4 + q) * 2) * 128, offr = 32 * ti + 8 * q;
             const bool pad = offr >= 152;                             // row-major rows: columns >= 152 + 4h are not read (zero)
-            const float4 a = *reinterpret_cast<const float4 *>(p + (rowmajor ? (pad ? 0 : offr) : off));
+            const float4 *src = reinterpret_cast<const float4 *>(p + (rowmajor ? (pad ? 0 : offr) : off));
+            const float4 a = NT ? ag_ld_nt(src) : *src;
             d[4 * q + 0] = a.x; d[4 * q + 1] = a.y; d[4 * q + 2] = a.z; d[4 * q + 3] = a.w;      // (padding quad: zeroed where the tile is consumed, zero_pad)
         }
     }
@@ -289,7 +291,7 @@ struct ResidInit {  // accumulator := Pn + h, i.e. W_pp[:, :F].enc + b_pp + resi
     __device__ __forceinline__ void prefetch() const
     {
 #pragma unroll
-        for (int t = 0; t < AG_NT; ++t) load_tile(hh, h_rowmajor, t, hraw[t]);
+        for (int t = 0; t < AG_NT; ++t) load_tile<true>(hh, h_rowmajor, t, hraw[t]);
         load_tile(pn, pn_rowmajor, 0, pnext);
     }
     __device__ __forceinline__ f32x16 operator()(int ti) const
@@ -1895,7 +1897,7 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
         const size_t pk = (size_t)blk * AG_PACK_BLOCK + h * 128 + j * 4;
         pn_ptr = pn_rows ? pn_rows + crow_cur : a.pn + pk;      // Pn (two L2-hot compact rows per sample in the reference's rollouts) is loaded where it is
 #pragma unroll                                                 // added: 16 registers per tile less in flight through the phase
-        for (int k = 0; k < N1; ++k) ResidInit::load_tile(h_rows ? h_rows + crow_cur : a.h + pk, h_rows != nullptr, t1[k], rh[k]);
+        for (int k = 0; k < N1; ++k) ResidInit::load_tile<true>(h_rows ? h_rows + crow_cur : a.h + pk, h_rows != nullptr, t1[k], rh[k]);
     };
     // Nothing that is still in flight is carried over the loop's back edge (the compiler's wait-count analysis answers a loop-carried pending load
     // with a full vmcnt(0) at the top of the body, previous phase's stores included): a phase issues the next block's loads at its top and turns
