@@ -224,6 +224,7 @@ void pack_layer_h3(std::vector<float> &dst, std::vector<uint32_t> &scales, const
 
 }  // namespace
 
+#define AG_MAX_PARTS 4      // batch parts (streams) of a rollout
 struct ag_model {
     ag_model_config cfg;
     float *dev = nullptr;       // all packed streams, one allocation
@@ -245,7 +246,7 @@ struct ag_model {
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
                                 // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
     int stagger = 1;            // offset the rollout streams by one encode stage (env AG_STAGGER=0 disables)
-    int split = 2;              // rollout batch parts run on separate streams (env AG_SPLIT, 1 = single stream)
+    int split = 0;              // rollout batch parts on separate streams ("rollout_streams" / env AG_SPLIT): 1..4, or 0 = by the workload (rollout_want)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     // CU partitioning of the rollout (env AG_CU_SPLIT / "cu_split"): the first `cu_split` CU-mask bits — cu_split / 8 CUs of EVERY
@@ -776,7 +777,10 @@ int ag_train_weight_grads_into(int n_layers, const float *const *dz, const int32
 int ag_set_option(ag_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(AG_ERR_ARG, "ag_set_option: null argument");
-    if (!strcmp(name, "rollout_streams")) m->split = value;
+    if (!strcmp(name, "rollout_streams")) {
+        if (value < 0 || value > AG_MAX_PARTS) return fail(AG_ERR_ARG, "ag_set_option: rollout_streams takes 0 (by the workload) or 1..%d, not %d", AG_MAX_PARTS, value);
+        m->split = value;
+    }
     else if (!strcmp(name, "fuse_aggregate")) {
         if (value != 0 && value != 2) return fail(AG_ERR_ARG, "ag_set_option: fuse_aggregate takes 0 (separate launch) or 2 (reduce inside node_update), not %d", value);
         m->fuse_agg = value;
@@ -943,7 +947,10 @@ static void carve_rollout(Carver &c, const ag_rollout_params *p, int B, AgFwdArg
 // and co-running kernel streams de-phase the memory-bound stages (segment reduce, edge-feature gathers, edge
 // build) of one part against the MFMA-bound stages of another — each part's persistent kernels take an equal
 // share of the resident-workgroup slots.
-#define AG_MAX_PARTS 4
+// "rollout_streams" 0: two streams hide launch gaps and overlap the MFMA-bound edge encoder of one half with the HBM-bound kernels of the other, but the halves
+// also evict each other's tables between a reduce and its node_update.  Measured with the r05 kernels (profiles/r05_nt_hints.txt, ab_streams): one stream wins where
+// the edge encoder is a third of the step (rope, top-k 10: +1-2 % at 256 graphs, +4 % at 1 024; cloth, top-k 5: even), two where it is 40 % (granular, top-k 20: +1.7 %).
+static int rollout_want(const ag_model *m, const ag_rollout_params *p) { return m && m->split > 0 ? m->split : (p->topk >= 16 ? 2 : 1); }
 static int rollout_parts(int B, int want)
 {
     int parts = want < 1 ? 1 : (want > AG_MAX_PARTS ? AG_MAX_PARTS : want);
@@ -980,6 +987,7 @@ static int ensure_partition(ag_model *m)
 }
 
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p) { return ag_rollout_workspace_bytes_for(nullptr, p); }
+int ag_rollout_streams_for(const ag_model *m, const ag_rollout_params *p) { return m && p ? rollout_parts(p->B, rollout_want(m, p)) : 0; }
 
 size_t ag_rollout_workspace_bytes_for(const ag_model *m, const ag_rollout_params *p)
 {
@@ -1017,7 +1025,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
     if (m->cfg.phys_dim > 0 && !phys) return fail(AG_ERR_ARG, "ag_rollout: phys is null");
     hipStream_t s0 = static_cast<hipStream_t>(stream);
     const int H = m->cfg.n_his, N = p->N, n_p = p->n_p, Pd = m->cfg.phys_dim;
-    const int parts = rollout_parts(p->B, m->split);
+    const int parts = rollout_parts(p->B, rollout_want(m, p));
     for (int k = 1; k < parts; ++k)
         if (!m->aux_stream[k]) {
             AG_HIP(hipStreamCreateWithFlags(&m->aux_stream[k], hipStreamNonBlocking));

@@ -242,7 +242,10 @@ class Engine:
         self.model.take_status = take
         status[0] |= int(self.model.take_status())
         assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and bool(torch.isfinite(out["state_seqs"]).all())
+        import ctypes
+        prm = _lib.RolloutParams(batch, wl["n_obj"] + synth.MATERIALS[self.material]["n_tools"], wl["n_obj"], 1, synth.MATERIALS[self.material]["topk"], 0, 0, T, 0, 0.0)
         res = {"B_global": B_global, "dt": dt, "ms_per_step": dt / steps * 1e3, "value": B_global * T * steps / dt,
+               "streams": int(self.L.ag_rollout_streams_for(self.h, ctypes.byref(prm))),
                "roofline": None, "roofline_hbm": None, "kernels": None, "model_status": status[0]}
         if timing:
             res["rank_ms"] = (agdist.elapsed_ms(timing["rollout"]) / steps, agdist.elapsed_ms(timing["gather"]) / steps)
@@ -372,7 +375,7 @@ def main():
                     help="engine arithmetic mode: f32 = exact fp32 MFMA, bf16x3 = split-bf16, fast (default) = bf16x3 node stacks + fp16 edge stack "
                          "with fp8 corrections + q16 table; all three hold the 1e-4 gate at any motion size with model_status 0 "
                          "(tests/test_gpu_parity.py, tools/fuzz_parity.py)")
-    ap.add_argument("--streams", type=int, default=2, help="rollout batch parts on separate streams (engine default 2)")
+    ap.add_argument("--streams", type=int, default=0, help="rollout batch parts on separate streams (0 = the engine's choice by workload, its default)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no engine: process group on gloo with CPU tensors, sharding, all-gather, timing reduction and the JSON line only "
                          "(launch-line / key contract of the multi-GPU run; the numbers are meaningless)")
@@ -478,7 +481,7 @@ def main():
                                    f"{args.material} {wl['n_obj']} particles, batch {per_gpu}/GPU"
                                    + (f" (global batch {r['B_global']} over {world} GPUs)" if args.global_batch else "") + f", {T}-step rollout",
                        "global_batch": r["B_global"], "rollout_steps": T, "parallelism": f"batch-shard x{world} + all-gather",
-                       "rollout_streams": args.streams, "weights": "seed-0 random init (reference default init)" if args.weights == "seed0" else
+                       "rollout_streams": r.get("streams", args.streams), "weights": "seed-0 random init (reference default init)" if args.weights == "seed0" else
                                   f"{args.weights} (the reference's train() on a toy dataset, tools/gen_trained.py)",
                        "precision": args.precision, "arithmetic": ARITH_SHORT[args.precision],
                        # 0 = no timed pass left the arithmetic's range (include/adaptigraph_hip.h: ag_model_status)

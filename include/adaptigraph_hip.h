@@ -58,7 +58,8 @@ int ag_model_update_weights(ag_model *m, const float *const *weights);
 int ag_model_destroy(ag_model *m);
 
 /* Engine knobs (all have sane defaults; used by bench.py for A/B passes):
- *   "rollout_streams"  1..4  ag_rollout runs the batch as this many independent parts on separate streams (2)
+ *   "rollout_streams"  0..4  ag_rollout runs the batch as this many independent parts on separate streams; 0 (default): the engine's choice by
+ *                            workload, see ag_rollout_streams_for
  *   "fuse_aggregate"   0/2   segment reduce as its own HBM-streaming kernel (0, default) or inside node_update through an LDS stage
  *                            (2, precision 2 only: no `agg` table; measured equal solo, -4 % in the two-stream rollout); bit-identical results
  *   "max_blocks"       n     persistent grid size (default 2 x #CUs)
@@ -143,6 +144,9 @@ typedef struct ag_rollout_params {
 
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p);
 size_t ag_rollout_workspace_bytes_for(const ag_model *m, const ag_rollout_params *p);
+/* Number of batch parts (one HIP stream each) ag_rollout will use for these parameters: the "rollout_streams" option, or with its default 0 the engine's
+ * choice by workload (one stream, two where the edge stack dominates: top-k >= 16), never more than B / 8. */
+int ag_rollout_streams_for(const ag_model *m, const ag_rollout_params *p);
 
 /*   state0 (B,n_his,N,3) initial history incl. tool slots; delta (B,N,3) per-step tool motion (graph["action"]);
  *   attrs (B,N,2); p_instance (B,n_p,n_instance); phys (B,phys_dim); mask/tool_mask (B,N) u8;

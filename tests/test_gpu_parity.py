@@ -744,6 +744,30 @@ def test_cu_partitioned_rollout_is_bitwise_the_shared_chip_rollout(weights, spli
         m.set_option("cu_split", 100)           # not a multiple of 8
 
 
+def test_rollout_stream_count_default_follows_the_workload_and_never_changes_a_bit(weights):
+    """"rollout_streams" 0 (the default): one stream, two where the edge stack dominates the step (top-k >= 16: granular), never more than B / 8
+    parts; 1..4 are taken as given (ag_rollout_streams_for reports what ag_rollout will do).  Graphs never interact: every count gives the same bits."""
+    import ctypes
+    m = make_model(weights, "rope", prec="fast")
+    L, h = _lib.lib(), m.handle(torch.device(DEV))
+
+    def parts(B, topk):
+        prm = _lib.RolloutParams(B, 301, 300, 1, topk, 0, 1, 4, 0, 0.0)
+        return L.ag_rollout_streams_for(h, ctypes.byref(prm))
+
+    assert (parts(256, 10), parts(256, 5), parts(256, 20), parts(12, 20), parts(4, 20)) == (1, 1, 2, 1, 1)
+    state, act = synth.make_mpc_inputs("rope", 300, 40, seed=9, len_lo=3, len_hi=5.9, spacing=0.1)
+    ref = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+    for n in (1, 2, 3, 4):
+        m.set_option("rollout_streams", n)
+        assert parts(256, 10) == n and parts(20, 10) == min(n, 2)
+        assert torch.equal(dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"], ref)
+    m.set_option("rollout_streams", 0)
+    assert parts(256, 10) == 1
+    with pytest.raises(RuntimeError):
+        m.set_option("rollout_streams", 5)
+
+
 def test_rollout_is_hip_graph_capturable(weights):
     """ag_rollout never synchronises the host and joins its auxiliary streams on every path, so a caller may capture it in a HIP graph
     (torch.cuda.graphs): the replayed rollout equals the enqueued one bit for bit, twice (replay is not faster, the point is
