@@ -156,9 +156,15 @@ __device__ __forceinline__ int ag_half_lane_feature(int c) { return 32 * (c >> 2
 // on the edge encoder's per-edge table stores 4 %, on the Hr / Hs stores 1-2 %; the sc0 / sc1 scope bits make no difference on any of them.
 typedef int ag_i32x4 __attribute__((ext_vector_type(4)));
 typedef float ag_f32x4 __attribute__((ext_vector_type(4)));
+#ifdef AG_NO_NT     // A/B builds (tools/ab_build.sh base="-DAG_NO_NT"): plain loads / stores
+__device__ __forceinline__ int4 ag_ld_nt(const int4 *p) { return *p; }
+__device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { return *p; }
+__device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { *p = v; }
+#else
 __device__ __forceinline__ int4 ag_ld_nt(const int4 *p) { const ag_i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_i32x4 *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { const ag_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_f32x4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin_nontemporal_store(ag_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ag_f32x4 *>(p)); }
+#endif
 
 template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
 __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
