@@ -140,7 +140,9 @@ __device__ __forceinline__ void ag_overflow_view(AgFwdArgs &a)
 {
     if (a.ovf && a.hr_full && *a.ovf != 0) { a.hr = const_cast<float *>(a.hr_full); a.hs = const_cast<float *>(a.hs_full); a.hr_row = nullptr; }
 }
+#ifndef AG_AGG_IN_FLIGHT
 #define AG_AGG_IN_FLIGHT 4
+#endif
 #define AG_AGG_GROUP 20             // lanes per node
 #define AG_AGG_NODES_PER_WAVE 3
 __device__ __forceinline__ int ag_half_lane_feature(int c) { return 32 * (c >> 2) + 8 * (2 * (c & 1)) + 4 * ((c >> 1) & 1); }
@@ -193,7 +195,7 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                t[i] = ag_ld_nt(&et[(size_t)(e + i) * (AG_FP / 8)]);
+                t[i] = ag_ld_nt(&et[(size_t)(e + i) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
                 if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
                 else {
                     u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
