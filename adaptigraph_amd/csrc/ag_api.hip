@@ -389,7 +389,7 @@ void carve_edges(Carver &c, AgEdgeArgs &a)
     a.sel = a.connect ? c.take<int32_t>(rows * a.cap) : nullptr;
     a.deg = c.take<int32_t>(rows);
     a.flag = c.take<int32_t>(a.B);
-    a.blk_sum = c.take<int32_t>(rows / 1024 + 2);
+    a.blk_sum = c.take<int32_t>(rows / 256 + 2);       // one partial sum per 256 rows (ag_edges.hip: kScanRows)
     a.grid_raw = c.take<int32_t>((size_t)a.B * 8);
     a.cell_start = c.take<int32_t>((size_t)a.B * 8193);
     a.sorted = c.take<float4>(rows);

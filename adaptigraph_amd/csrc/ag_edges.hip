@@ -619,64 +619,57 @@ __global__ __launch_bounds__(256) void finalize_connect_sweep_kernel(AgEdgeArgs 
 }
 
 // ---- exclusive scan of the per-row degrees -> row_ptr, then COO fill -----------------------------
-constexpr int kScanRows = 1024;   // rows per block (256 threads x 4)
+constexpr int kScanRows = 256;    // rows per block (one per thread; ag_api.hip sizes blk_sum with the same number)
 
 __global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a)
 {
     const int rows = a.B * a.N;
-    const int r0 = blockIdx.x * kScanRows + threadIdx.x * 4;
-    int s = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s += (r0 + u < rows) ? a.deg[r0 + u] : 0;
+    const int r = blockIdx.x * kScanRows + threadIdx.x;
     int total;
-    block_exclusive_scan(s, &total);
+    block_exclusive_scan(r < rows ? a.deg[r] : 0, &total);
     if (threadIdx.x == 0) a.blk_sum[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(256) void scan_blocks_kernel(AgEdgeArgs a, int nblk)
+// Second and last pass: a block's base offset is the sum of the partial sums in front of it (every block adds them up itself: nblk values, 1 001 at
+// 256 x 1 001 rows — cheaper than a one-workgroup launch that scans them), then row_ptr of its 256 rows and, from LDS, their COO entries: one
+// thread per (row, slot), coalesced reads of the per-row sender lists, near-coalesced writes, four slots' loads in flight per thread.
+// (r05: was scan_blocks + rowptr + scatter, three launches of 5 + 5 + 11 us at C2.)
+__global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
 {
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nblk; base += 256) {
-        const int idx = base + threadIdx.x;
-        const int v = idx < nblk ? a.blk_sum[idx] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total);
-        const int c = carry;
-        if (idx < nblk) a.blk_sum[idx] = c + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.row_ptr[a.B * a.N] = carry;
-}
-
-__global__ __launch_bounds__(256) void rowptr_kernel(AgEdgeArgs a)
-{
+    __shared__ int s_ptr[kScanRows], s_deg[kScanRows];
     const int rows = a.B * a.N;
-    const int r0 = blockIdx.x * kScanRows + threadIdx.x * 4;
-    int d[4], s = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { d[u] = (r0 + u < rows) ? a.deg[r0 + u] : 0; s += d[u]; }
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += a.blk_sum[i];
+    int base;
+    block_exclusive_scan(part, &base);
+    const int r = blockIdx.x * kScanRows + threadIdx.x;
+    const int d = r < rows ? a.deg[r] : 0;
     int total;
-    int off = a.blk_sum[blockIdx.x] + block_exclusive_scan(s, &total);
+    const int off = base + block_exclusive_scan(d, &total);
+    s_ptr[threadIdx.x] = off;
+    s_deg[threadIdx.x] = d;
+    if (r < rows) a.row_ptr[r] = off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.row_ptr[rows] = base + total;
+    __syncthreads();
+    const int row0 = blockIdx.x * kScanRows;
+    const int nloc = rows - row0 < kScanRows ? rows - row0 : kScanRows;
+    const int32_t *src = sel + (size_t)row0 * cap;
+    const int n = nloc * cap;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+        int v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (r0 + u < rows) { a.row_ptr[r0 + u] = off; off += d[u]; }
-}
-
-// one thread per (row, slot): coalesced read of the per-row sender lists, near-coalesced COO writes
-__global__ __launch_bounds__(256) void scatter_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
-{
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long rows = (long long)a.B * a.N;
-    if (idx >= rows * cap) return;
-    const int row = (int)(idx / cap), slot = (int)(idx - (long long)row * cap);
-    if (slot >= a.deg[row]) return;
-    const int e = a.row_ptr[row] + slot;
-    a.edge_recv[e] = row;
-    a.edge_send[e] = (row / a.N) * a.N + sel[idx];
+        for (int u = 0; u < 4; ++u) v[u] = i0 + 256 * u < n ? src[i0 + 256 * u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + 256 * u;
+            if (idx >= n) break;
+            const int lr = idx / cap, slot = idx - lr * cap;
+            if (slot >= s_deg[lr]) continue;
+            const int row = row0 + lr, e = s_ptr[lr] + slot;
+            a.edge_recv[e] = row;
+            a.edge_send[e] = (row / a.N) * a.N + v[u];
+        }
+    }
 }
 
 }  // namespace
@@ -722,8 +715,5 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     }
     const int nblk = (rows + kScanRows - 1) / kScanRows;
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, a, nblk);
-    hipLaunchKernelGGL(rowptr_kernel, dim3(nblk), dim3(256), 0, s, a);
-    const long long slots = (long long)rows * cap;
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, a, sel, cap);
+    hipLaunchKernelGGL(rowptr_scatter_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
 }

@@ -5,6 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}; cd $REPO; EV=$REPO/gpurun_out/ev5; rm -rf $
 python -c "import torch" 2>/dev/null
 python bench.py --steps 20 --warmup 5 > $EV/r05_bench.json 2> $EV/bench.err
 python bench.py --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-extra > $EV/r05_bench_1stream.json 2>> $EV/bench.err
+python bench.py --steps 5 --warmup 2 --streams 2 --no-cpu-baseline --no-extra > $EV/r05_bench_2streams.json 2>> $EV/bench.err
 # BASELINE configs[3] at its global batch on one GPU (8 GPUs would take 64 graphs each)
 python bench.py --material cloth --global-batch 512 --rollout-steps 20 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $EV/r05_bench_cloth512.json 2>> $EV/bench.err
 python tools/fwd_err.py > $EV/r05_fwd_err.txt 2>/dev/null
