@@ -465,7 +465,7 @@ void run_edge_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
     // row-tile claim counter of the STREAMING edge encoders; the weight-stationary kernel (default mode) deals its blocks statically: no fill launch
     const bool ws = a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2 && a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL;
     if (a.tile_ctr && !ws) (void)hipMemsetAsync(a.tile_ctr, 0, sizeof(int), s);
-    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup) ag_launch_send_remap(a, s); }
+    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup && !ws) ag_launch_send_remap(a, s); }      // (ws: mapped by the node-table launch)
 }
 
 void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)

@@ -876,12 +876,13 @@ __global__ __launch_bounds__(256) void node_classify_kernel(AgFwdArgs a)
 }
 
 // step 2 (independent of the encoders): the first round's sender gathers go to compact rows, so the sender column is mapped once
-__global__ __launch_bounds__(256) void send_remap_kernel(AgFwdArgs a)
+__device__ __forceinline__ void send_remap_body(const AgFwdArgs &a, int block, int nblocks)
 {
     const int E = a.row_ptr[a.B * a.N];
     const bool ovf = *a.ovf != 0;                // the call overflowed the compact tables: round 0 gathers the full-size sender table by node id
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) a.send_c[e] = ovf ? a.edge_send[e] : a.node_row[a.edge_send[e]];
+    for (int e = block * 256 + threadIdx.x; e < E; e += nblocks * 256) a.send_c[e] = ovf ? a.edge_send[e] : a.node_row[a.edge_send[e]];
 }
+__global__ __launch_bounds__(256) void send_remap_kernel(AgFwdArgs a) { send_remap_body(a, blockIdx.x, gridDim.x); }
 
 template <class Prec, bool DEDUP>
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_encode_kernel(AgWeights w, AgFwdArgs a)
@@ -1284,8 +1285,11 @@ __device__ __forceinline__ void ws_round_barrier() { asm volatile("s_waitcnt lgk
 // gather is two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].
 // The per-edge features are then plain differences of two rows — the same subtractions in the same order as
 // (pr[i+1] - pr[i]) - (ps[i+1] - ps[i]) in edge_features.
-__global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a)
+// Workgroups past the node range (de-duplicated calls) map the sender column to compact rows for round 0's reduce (send_remap_body): one small
+// launch per model step instead of two.
+__global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a, int nb_tab)
 {
+    if ((int)blockIdx.x >= nb_tab) { send_remap_body(a, (int)blockIdx.x - nb_tab, (int)gridDim.x - nb_tab); return; }
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= a.B * a.N) return;
     const int b = g / a.N, i = g - b * a.N;
@@ -2228,7 +2232,8 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
-            hipLaunchKernelGGL(edge_node_tab_kernel, dim3((a.B * a.N + 255) / 256), dim3(256), 0, s, a);
+            const int nb_tab = (a.B * a.N + 255) / 256, nb_map = a.dedup ? ((a.e_cap + 255) / 256 < 2048 ? (a.e_cap + 255) / 256 : 2048) : 0;
+            hipLaunchKernelGGL(edge_node_tab_kernel, dim3(nb_tab + nb_map), dim3(256), 0, s, a, nb_tab);
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);   // (always eight waves, whatever AG_MLP_THREADS is)
             return;
         }
