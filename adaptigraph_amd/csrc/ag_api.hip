@@ -539,7 +539,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     }
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
-    if (const char *v = getenv("AG_NODE_WS")) m->node_ws = atoi(v) & 3;
+    if (const char *v = getenv("AG_NODE_WS")) m->node_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
@@ -792,7 +792,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
         m->edge_products = value;
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
-    else if (!strcmp(name, "node_stationary")) m->node_ws = value & 3;       // bit 0: the rounds before the last, bit 1: the decoder round
+    else if (!strcmp(name, "node_stationary")) m->node_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "cu_split")) {
         if (value != 0 && (value < 8 || value > m->n_cus - 8 || (value & 7)))

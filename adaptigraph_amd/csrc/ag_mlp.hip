@@ -1994,254 +1994,6 @@ __global__ __launch_bounds__(256, 1) void node_update_nws_kernel(AgWeights w, Ag
     else nws_wave<3, HSQ>(w, a, sX, sY);
 }
 
-// =====================================================================================================================
-// Weight-STATIONARY decoder round (precision modes 1 / 2; ag_set_option("node_stationary", 3)): particle_effect' = relu(W_pp[:, F:] agg + Pn + h), the
-// decoder's three layers, clamp + integrate — 16 (layer, out-tile) units, four per wave, all in registers for the whole launch; nothing is stored
-// but the predicted positions.  32-row blocks flow through FOUR stages, one barrier per block:
-//     phase p:   first layer of block p       set X[p & 1]        -> Y1[p & 1]           (acc = Pn + h, ReLU)
-//                linear_0 of block p - 1      set Y1[(p - 1) & 1] -> Y2[(p - 1) & 1]     (bias column, ReLU)
-//                linear_1 of block p - 2      set Y2[p & 1]       -> Y3[p & 1]           (bias column, ReLU)
-//                linear_2 of block p - 3      set Y3[(p - 1) & 1] -> clamp, integrate, pred_pos / pred_motion
-//                agg rows of block p + 1: loaded at the top, split and written to X[(p + 1) & 1] at the end (as in the kernel above)
-// Wave w owns out-tile w of the first three layers (accumulation registers) and one more unit (architectural registers): wave 3 the first layer's
-// fifth tile, wave 0 linear_0's, wave 1 linear_1's, wave 2 linear_2.  A wave runs its four units as TWO passes of two interleaved accumulators, each
-// unit reading its OWN set (nws_pass2): the version of R5.2b ran them as four short dependent passes and lost.  Eight 20 KB sets = all 160 KB of LDS.
-// Every accumulator sees its k16-steps and products in node_update_kernel<PrecB3, LAST>'s order (the bias column is feature 150 := 1.0 of the input set,
-// written by the producer of its fifth tile): the same bits.
-// =====================================================================================================================
-__device__ __forceinline__ void nws_fake2(f32x16 &a0, f32x16 &a1, const bf16x8 &p, const bf16x8 &q, const bf16x8 &r, const bf16x8 &t) { asm volatile("" : "+v"(a0), "+v"(a1) : "v"(p), "v"(q), "v"(r), "v"(t)); }
-// two units' k16-step with the six matrix instructions alternating between the accumulators (each accumulator still sees lo.xh, hi.xl, hi.xh in order)
-template <bool ACC0, bool ACC1>
-__device__ __forceinline__ void nws_mfma3x2(f32x16 &a0, f32x16 &a1, const bf16x8 &w0h, const bf16x8 &w0l, const bf16x8 &w1h, const bf16x8 &w1l,
-                                            const bf16x8 &x0h, const bf16x8 &x0l, const bf16x8 &x1h, const bf16x8 &x1l)
-{
-#define AG_ILV_BODY "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %3, %6, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %5, %8, %1\n\t" \
-                    "v_mfma_f32_32x32x16_bf16 %0, %2, %7, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %9, %1\n\t" \
-                    "v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %8, %1"
-    if constexpr (ACC0 && ACC1) asm volatile(AG_ILV_BODY : "+v"(a0), "+v"(a1) : "a"(w0h), "a"(w0l), "a"(w1h), "a"(w1l), "v"(x0h), "v"(x0l), "v"(x1h), "v"(x1l));
-    else if constexpr (ACC0) asm volatile(AG_ILV_BODY : "+v"(a0), "+v"(a1) : "a"(w0h), "a"(w0l), "v"(w1h), "v"(w1l), "v"(x0h), "v"(x0l), "v"(x1h), "v"(x1l));
-    else asm volatile(AG_ILV_BODY : "+v"(a0), "+v"(a1) : "v"(w0h), "v"(w0l), "v"(w1h), "v"(w1l), "v"(x0h), "v"(x0l), "v"(x1h), "v"(x1l));
-#undef AG_ILV_BODY
-}
-template <bool ACC0, bool ACC1>
-__device__ __forceinline__ void nws_pass2(f32x16 &acc0, f32x16 &acc1, const NwsUnit &W0, const NwsUnit &W1, unsigned la0, unsigned la1)
-{
-    bf16x8 xa[3][2], xb[3][2];
-    lds_read16<0>(xa[0][0], la0);
-    lds_read16<1024>(xa[0][1], la0);
-    lds_read16<0>(xb[0][0], la1);
-    lds_read16<1024>(xb[0][1], la1);
-    lds_read16<2048>(xa[1][0], la0);
-    lds_read16<3072>(xa[1][1], la0);
-    lds_read16<2048>(xb[1][0], la1);
-    lds_read16<3072>(xb[1][1], la1);
-    static_for<0, 10>([&](auto UU) {
-        constexpr int u = decltype(UU)::value;
-        if constexpr (u + 2 < 10) {
-            lds_read16<(2 * (u + 2)) * 1024>(xa[(u + 2) % 3][0], la0);
-            lds_read16<(2 * (u + 2) + 1) * 1024>(xa[(u + 2) % 3][1], la0);
-            lds_read16<(2 * (u + 2)) * 1024>(xb[(u + 2) % 3][0], la1);
-            lds_read16<(2 * (u + 2) + 1) * 1024>(xb[(u + 2) % 3][1], la1);
-        }
-        constexpr int ahead = (9 - u) < 2 ? (9 - u) : 2;      // steps whose four reads were issued after step u's
-#if defined(AG_X_NWL_NOMFMA)
-        lds_wait_pair<4 * ahead>(xb[u % 3][0], xb[u % 3][1]);
-        nws_fake2(acc0, acc1, xa[u % 3][0], xa[u % 3][1], xb[u % 3][0], xb[u % 3][1]);
-#elif defined(AG_X_NWL_ILV)
-        lds_wait_pair<4 * ahead>(xb[u % 3][0], xb[u % 3][1]);
-        nws_mfma3x2<ACC0, ACC1>(acc0, acc1, W0.hi[u], W0.lo[u], W1.hi[u], W1.lo[u], xa[u % 3][0], xa[u % 3][1], xb[u % 3][0], xb[u % 3][1]);
-#else
-        lds_wait_pair<2 + 4 * ahead>(xa[u % 3][0], xa[u % 3][1]);
-        nws_mfma3<ACC0>(acc0, W0.hi[u], W0.lo[u], xa[u % 3][0], xa[u % 3][1]);
-        lds_wait_pair<4 * ahead>(xb[u % 3][0], xb[u % 3][1]);
-        nws_mfma3<ACC1>(acc1, W1.hi[u], W1.lo[u], xb[u % 3][0], xb[u % 3][1]);
-#endif
-    });
-    nws_settle(acc0);
-    nws_settle(acc1);
-}
-// ReLU'd out-tile `tile` of a layer -> k16-steps 2 tile, 2 tile + 1 of the next layer's input set; BIASCOL: the tile holds feature 150, the bias column of the
-// consuming layer (PrecB3::layer: feature K = 16 * 9 + 6 -> element 2 of lane half 1 in k16-step 9 := 1.0 exactly)
-template <bool BIASCOL>
-__device__ __forceinline__ void nwl_write_tile(unsigned char *set_lane, int tile, const f32x16 &v, int h)
-{
-#ifdef AG_X_NWL_NOEPI
-    if (h == 77) *reinterpret_cast<float *>(set_lane) = v[0] + v[5] + v[9] + v[15];
-    return;
-#endif
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh) {
-        float x[8] = {v[8 * sh], v[8 * sh + 1], v[8 * sh + 2], v[8 * sh + 3], v[8 * sh + 4], v[8 * sh + 5], v[8 * sh + 6], v[8 * sh + 7]};
-        if constexpr (BIASCOL) { if (sh == 1 && h == 1) x[2] = 1.0f; }
-        nws_write_half(set_lane, 2 * tile + sh, x);
-    }
-}
-
-template <int WAVE>
-__device__ __forceinline__ void nwl_wave(const AgWeights &w, const AgFwdArgs &a, unsigned char *sX, unsigned char *sY1, unsigned char *sY2, unsigned char *sY3)
-{
-    constexpr int N1 = WAVE == 3 ? 2 : 1;      // first-layer tiles of this wave (wave 3: tiles 3 and 4)
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int Mn = a.B * a.N;
-    const int nblk = (Mn + 31) / 32;
-    const int n_i = ((int)blockIdx.x < nblk) ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    if (n_i == 0) return;                      // (workgroup-uniform)
-    const bool ovf = a.ovf && *a.ovf != 0;
-    const float *pn_rows = ovf ? nullptr : a.pn_rows, *h_rows = ovf ? nullptr : a.h_rows;
-    NwsUnit UA, UB, UC, UD;
-    const float4 *ws = w.node_last_b3;
-    nws_load_unit<true>(UA, ws + (size_t)(0 + WAVE) * AG_CHUNK_F4, lane);
-    nws_load_unit<true>(UB, ws + (size_t)(5 + WAVE) * AG_CHUNK_F4, lane);
-    nws_load_unit<true>(UC, ws + (size_t)(10 + WAVE) * AG_CHUNK_F4, lane);
-    constexpr int chunk_d = WAVE == 3 ? 4 : WAVE == 0 ? 9 : WAVE == 1 ? 14 : 15;
-    nws_load_unit<false>(UD, ws + (size_t)chunk_d * AG_CHUNK_F4, lane);
-    const int t1[2] = {WAVE, 4};
-    auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
-    constexpr int NS = WAVE < 2 ? 3 : 2;
-    float4 raw[NS][2];
-    auto stage_load = [&](int i) {
-        const size_t g = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
-        const float *row = a.agg + g * AG_FP + 4 * h;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int u = WAVE + 4 * k;
-            raw[k][0] = *reinterpret_cast<const float4 *>(row + 16 * u);
-            raw[k][1] = *reinterpret_cast<const float4 *>(row + 16 * u + 8);
-        }
-    };
-    auto stage_write = [&](unsigned char *set) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const float x[8] = {raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w};
-            nws_write_half(set + lane * 16, WAVE + 4 * k, x);
-        }
-    };
-    f32x16 rh[N1];
-    const float *pn_ptr = nullptr;
-    int idx_raw = 0;
-    const int32_t *idx_tab = pn_rows ? a.node_row : a.row_ptr;
-    size_t crow_cur = 0;
-    auto idx_load = [&](int i) {
-        const size_t g = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
-        idx_raw = idx_tab[g < (size_t)Mn ? g : 0];
-    };
-    auto resid_load = [&](int i) {
-        const int blk = i < n_i ? gblock(i) : 0;
-        const size_t pk = (size_t)blk * AG_PACK_BLOCK + h * 128 + j * 4;
-        pn_ptr = pn_rows ? pn_rows + crow_cur : a.pn + pk;
-#pragma unroll
-        for (int k = 0; k < N1; ++k) ResidInit::load_tile<true>(h_rows ? h_rows + crow_cur : a.h + pk, h_rows != nullptr, t1[k], rh[k]);
-    };
-    f32x16 acc1[N1];
-    auto resid_to_acc = [&]() {
-#pragma unroll
-        for (int k = 0; k < N1; ++k) {
-            f32x16 rp;
-            ResidInit::load_tile(pn_ptr, pn_rows != nullptr, t1[k], rp);
-            ResidInit::zero_pad(pn_rows != nullptr, t1[k], rp);
-            ResidInit::zero_pad(h_rows != nullptr, t1[k], rh[k]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[k][r] = rp[r] + rh[k][r];
-        }
-    };
-    auto relu16 = [](f32x16 &v) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = relu1(v[r]);
-    };
-    auto zero16 = [](f32x16 &v) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = 0.0f;
-    };
-    idx_load(0);
-    crow_cur = (size_t)idx_raw * AG_FP + 4 * h;
-    stage_load(0);
-    resid_load(0);
-    idx_load(1);
-    stage_write(sX);
-    resid_to_acc();
-    crow_cur = (size_t)idx_raw * AG_FP + 4 * h;          // block 1
-    __syncthreads();
-#pragma unroll 1
-    for (int p = 0; p < n_i + 3; ++p) {
-        const int q = p & 1;
-        unsigned char *X = sX + q * AG_NWS_SET, *Xn = sX + (q ^ 1) * AG_NWS_SET;
-        unsigned char *Y1w = sY1 + q * AG_NWS_SET, *Y1r = sY1 + (q ^ 1) * AG_NWS_SET;
-        unsigned char *Y2w = sY2 + (q ^ 1) * AG_NWS_SET, *Y2r = sY2 + q * AG_NWS_SET;
-        unsigned char *Y3w = sY3 + q * AG_NWS_SET, *Y3r = sY3 + (q ^ 1) * AG_NWS_SET;
-        const unsigned lX = lds_addr_of(X) + lane * 16, lY1 = lds_addr_of(Y1r) + lane * 16, lY2 = lds_addr_of(Y2r) + lane * 16, lY3 = lds_addr_of(Y3r) + lane * 16;
-        if (p + 1 < n_i) { stage_load(p + 1); resid_load(p + 1); idx_load(p + 2); }
-        // this phase's block of linear_2 (wave 2): the particle's current position, read at the top like every other load of the phase
-        float cur[3] = {0.f, 0.f, 0.f};
-        bool out_ok = false;
-        size_t out_at = 0;
-        if constexpr (WAVE == 2) {
-            if (p >= 3 && p - 3 < n_i) {
-                const int g = gblock(p - 3) * 32 + j;
-                if (g < Mn && h == 0) {
-                    const int b = g / a.N, i = g - b * a.N;
-                    if (i < a.n_p) {
-                        out_ok = true;
-                        out_at = ((size_t)b * a.n_p + i) * 3;
-                        const float *c0 = a.state + (((size_t)b * AG_NHIS + (AG_NHIS - 1)) * a.N + i) * 3;
-                        cur[0] = c0[0]; cur[1] = c0[1]; cur[2] = c0[2];
-                    }
-                }
-            }
-        }
-        f32x16 acc[2];
-        if constexpr (WAVE == 3) {
-            // pass 1: both first-layer tiles of the wave over X; pass 2: linear_0 tile 3 (Y1) and linear_1 tile 3 (Y2)
-            nws_layer<2, true, false, false>(acc1, UA, UD, UD, lX);
-            relu16(acc1[0]); relu16(acc1[1]);
-            nwl_write_tile<false>(Y1w + lane * 16, 3, acc1[0], h);
-            nwl_write_tile<true>(Y1w + lane * 16, 4, acc1[1], h);
-            zero16(acc[0]); zero16(acc[1]);
-            nws_pass2<true, true>(acc[0], acc[1], UB, UC, lY1, lY2);
-            relu16(acc[0]); relu16(acc[1]);
-            nwl_write_tile<false>(Y2w + lane * 16, 3, acc[0], h);
-            nwl_write_tile<false>(Y3w + lane * 16, 3, acc[1], h);
-        } else {
-            // pass 1: first-layer tile w (X) and linear_0 tile w (Y1)
-            zero16(acc[0]);
-            nws_pass2<true, true>(acc1[0], acc[0], UA, UB, lX, lY1);
-            relu16(acc1[0]); relu16(acc[0]);
-            nwl_write_tile<false>(Y1w + lane * 16, WAVE, acc1[0], h);
-            nwl_write_tile<false>(Y2w + lane * 16, WAVE, acc[0], h);
-            // pass 2: linear_1 tile w (Y2) and the wave's fourth unit
-            zero16(acc[0]); zero16(acc[1]);
-            if constexpr (WAVE == 0) nws_pass2<true, false>(acc[0], acc[1], UC, UD, lY2, lY1);              // linear_0 tile 4
-            else if constexpr (WAVE == 1) nws_layer<2, true, false, false>(acc, UC, UD, UD, lY2);            // linear_1 tile 4
-            else nws_pass2<true, false>(acc[0], acc[1], UC, UD, lY2, lY3);                                  // linear_2
-            relu16(acc[0]);
-            nwl_write_tile<false>(Y3w + lane * 16, WAVE, acc[0], h);
-            if constexpr (WAVE == 0) { relu16(acc[1]); nwl_write_tile<true>(Y2w + lane * 16, 4, acc[1], h); }
-            if constexpr (WAVE == 1) { relu16(acc[1]); nwl_write_tile<true>(Y3w + lane * 16, 4, acc[1], h); }
-        }
-        if (p + 1 < n_i) { stage_write(Xn); resid_to_acc(); crow_cur = (size_t)idx_raw * AG_FP + 4 * h; }
-        if constexpr (WAVE == 2) {
-            if (out_ok) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float mv = acc[1][c];
-                    a.pred_motion[out_at + c] = mv;
-                    a.pred_pos[out_at + c] = cur[c] + fminf(fmaxf(mv, -a.clamp), a.clamp);   // model.py:309
-                }
-            }
-        }
-        ws_round_barrier();
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void node_update_nwl_kernel(AgWeights w, AgFwdArgs a)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char sX[2 * AG_NWS_SET], sY1[2 * AG_NWS_SET], sY2[2 * AG_NWS_SET], sY3[2 * AG_NWS_SET];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) nwl_wave<0>(w, a, sX, sY1, sY2, sY3);
-    else if (wave == 1) nwl_wave<1>(w, a, sX, sY1, sY2, sY3);
-    else if (wave == 2) nwl_wave<2>(w, a, sX, sY1, sY2, sY3);
-    else nwl_wave<3>(w, a, sX, sY1, sY2, sY3);
-}
-
 // =====================================================================================================
 // Training path: the dense stacks of DynamicsPredictor.forward and their backward on the
 // same fused-layer machinery, in either arithmetic: exact fp32 MFMA (PrecF32) or split-bf16 (PrecB3: 2^-17 relative operand
@@ -2497,12 +2249,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hipStream_t s)
 {
     const dim3 grid(grid_for(a.B * a.N, a.max_blocks)), block(AG_MLP_THREADS);
-    if (a.precision == AG_PREC_B3 && last && (a.node_ws & 2) && !a.fuse_agg) {      // weight-stationary decoder round: one workgroup per CU
-        const int cus = a.max_blocks / AG_MLP_WG_PER_CU > 0 ? a.max_blocks / AG_MLP_WG_PER_CU : 1, nblk = (a.B * a.N + 31) / 32;
-        hipLaunchKernelGGL(node_update_nwl_kernel, dim3(nblk < cus ? nblk : cus), dim3(256), 0, s, w, a);
-        return;
-    }
-    if (a.precision == AG_PREC_B3 && !last && (a.node_ws & 1) && !a.fuse_agg) {      // weight-stationary kernel: one workgroup per CU
+    if (a.precision == AG_PREC_B3 && !last && a.node_ws && !a.fuse_agg) {      // weight-stationary kernel: one workgroup per CU
         const int cus = a.max_blocks / AG_MLP_WG_PER_CU > 0 ? a.max_blocks / AG_MLP_WG_PER_CU : 1, nblk = (a.B * a.N + 31) / 32;
         const dim3 g2(nblk < cus ? nblk : cus);
         if (a.hs_out_q16) hipLaunchKernelGGL(node_update_nws_kernel<true>, g2, dim3(256), 0, s, w, a);

@@ -319,18 +319,15 @@ def test_weight_stationary_node_update_is_bitwise_the_streaming_kernel(weights, 
     kw2 = {"action": t(g["action"]), material + "_physics_param": t(g["phys"])}
     m.set_option("node_stationary", 0)
     pos0, ref = m(*args, **kw2)
-    for ns in (1, 3, 2):        # bit 0: the rounds before the last, bit 1: the decoder round (four-stage pipeline, sixteen units)
-        m.set_option("node_stationary", ns)
-        for _ in range(5 if ns != 2 else 2):
-            pos1, out = m(*args, **kw2)
-            assert torch.isfinite(out).all() and torch.equal(ref, out) and torch.equal(pos0, pos1), ns
+    m.set_option("node_stationary", 1)
+    for _ in range(5):
+        pos1, out = m(*args, **kw2)
+        assert torch.isfinite(out).all() and torch.equal(ref, out) and torch.equal(pos0, pos1)
     if material == "rope" and n_obj == 1000:
         state, act = synth.make_mpc_inputs("rope", 300, 24, seed=6, len_lo=3, len_hi=5.9, spacing=0.1)
+        on = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
         m.set_option("node_stationary", 0)
-        off = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
-        for ns in (1, 3):
-            m.set_option("node_stationary", ns)
-            assert torch.equal(off, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]), ns
+        assert torch.equal(on, dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"])
     assert m.take_status() == 0
 
 
