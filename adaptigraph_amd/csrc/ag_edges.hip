@@ -181,10 +181,43 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *pos = a.pos + (size_t)b * a.pos_stride;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    // The sample's particles are read ONCE, all loads of a thread in flight together (up to kBinK per thread: N <= 4 352), and the three passes below
+    // run from registers; a plain `if (mk[j]) ... pos[j]` loop per pass is a chain of dependent round trips (r05: 16 -> 8 us at 256 x 1 001).
+    constexpr int kBinK = 17;
+    const bool cached = N <= 256 * kBinK;
+    float px[kBinK], py[kBinK], pz[kBinK];
+    unsigned vbits = 0, tbits = 0;
+    if (cached) {
+        unsigned char mv[kBinK], tv[kBinK];
+#pragma unroll
+        for (int i = 0; i < kBinK; ++i) {
+            const int j = tid + 256 * i, jc = j < N ? j : 0;
+            mv[i] = mk[jc]; tv[i] = tl[jc];
+            px[i] = pos[jc * 3]; py[i] = pos[jc * 3 + 1]; pz[i] = pos[jc * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < kBinK; ++i) {
+            if (tid + 256 * i < N && mv[i]) vbits |= 1u << i;
+            if (tv[i]) tbits |= 1u << i;
+        }
+    }
+    // f(j, x, y, z, is_tool) for every valid particle of this thread
+    auto for_valid = [&](auto &&f) {
+        if (cached) {
+#pragma unroll
+            for (int i = 0; i < kBinK; ++i)
+                if (vbits >> i & 1u) f(tid + 256 * i, px[i], py[i], pz[i], (tbits >> i & 1u) != 0);
+        } else {
+            for (int j = tid; j < N; j += 256)
+                if (mk[j]) f(j, pos[j * 3], pos[j * 3 + 1], pos[j * 3 + 2], tl[j] != 0);
+        }
+    };
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int j = tid; j < N; j += 256)
-        if (mk[j])
-            for (int c = 0; c < 3; ++c) { const float v = pos[j * 3 + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+    for_valid([&](int, float x, float y, float z, bool) {
+        lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+        lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+        lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+    });
     for (int c = 0; c < 3; ++c) {
         for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
         if (lane == 0) { red[c][wave] = lo[c]; red[3 + c][wave] = hi[c]; }
@@ -223,12 +256,10 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     const int ncell = g.nx * g.ny * g.nz;
     for (int c = tid; c < ncell; c += 256) cnt[c] = 0;
     __syncthreads();
-    for (int j = tid; j < N; j += 256)
-        if (mk[j]) {
-            const int cid = (cell_coord(pos[j * 3 + 2], g.z0, g.inv, g.nz) * g.ny + cell_coord(pos[j * 3 + 1], g.y0, g.inv, g.ny)) * g.nx +
-                            cell_coord(pos[j * 3], g.x0, g.inv, g.nx);
-            atomicAdd(&cnt[cid], 1);
-        }
+    for_valid([&](int, float x, float y, float z, bool) {
+        const int cid = (cell_coord(z, g.z0, g.inv, g.nz) * g.ny + cell_coord(y, g.y0, g.inv, g.ny)) * g.nx + cell_coord(x, g.x0, g.inv, g.nx);
+        atomicAdd(&cnt[cid], 1);
+    });
     __syncthreads();
     // exclusive scan of cnt[0..ncell): thread t owns cells [t*32, t*32+32)
     int local = 0;
@@ -245,13 +276,11 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     if (tid == 0) { cs_out[ncell] = total; GridParams out = g; out.total = total; reinterpret_cast<GridParams *>(a.grid_raw)[b] = out; }
     __syncthreads();
     float4 *sorted = a.sorted + (size_t)b * N;
-    for (int j = tid; j < N; j += 256)
-        if (mk[j]) {
-            const float x = pos[j * 3], y = pos[j * 3 + 1], z = pos[j * 3 + 2];
-            const int cid = (cell_coord(z, g.z0, g.inv, g.nz) * g.ny + cell_coord(y, g.y0, g.inv, g.ny)) * g.nx + cell_coord(x, g.x0, g.inv, g.nx);
-            const int p = atomicAdd(&cnt[cid], 1);
-            sorted[p] = make_float4(x, y, z, __int_as_float(j | (tl[j] ? 0x40000000 : 0)));
-        }
+    for_valid([&](int j, float x, float y, float z, bool tool) {
+        const int cid = (cell_coord(z, g.z0, g.inv, g.nz) * g.ny + cell_coord(y, g.y0, g.inv, g.ny)) * g.nx + cell_coord(x, g.x0, g.inv, g.nx);
+        const int p = atomicAdd(&cnt[cid], 1);
+        sorted[p] = make_float4(x, y, z, __int_as_float(j | (tool ? 0x40000000 : 0)));
+    });
 }
 
 __global__ __launch_bounds__(256) void select_cells_kernel(AgEdgeArgs a)
@@ -471,22 +500,30 @@ __global__ __launch_bounds__(256, 4) void select_lanes_packed_kernel(AgEdgeArgs 
             if (z2 < 0 || z2 >= g.nz || y2 < 0 || y2 >= g.ny) continue;
             const int base = (z2 * g.ny + y2) * g.nx;
             const int p1 = cstart[base + x_hi + 1];
-            for (int p = cstart[base + x_lo]; p < p1; ++p) {
-                const float4 sj = sorted[p];
-                const int w = __float_as_int(sj.w);
-                const float dx = xi - sj.x, dy = yi - sj.y, dz = zi - sj.z;
-                float d = (dx * dx + dy * dy) + dz * dz;
-                if (ti && (w & 0x40000000)) d = 1e10f;
-                if ((d - thr) < 0.0f) {
-                    const unsigned qd = min((unsigned)(d * qscale), qtop);      // monotone in d (d >= 0; a NaN never gets here)
-                    unsigned key = (qd << jb) | (unsigned)(w & 0x3fffffff);
+            // candidates four at a time, their loads in flight together (one load, then its tests, per trip was a memory round trip per candidate)
+            for (int p = cstart[base + x_lo]; p < p1; p += 4) {
+                float4 sq[4];
 #pragma unroll
-                    for (int s = 0; s <= K; ++s) {
-                        const unsigned lo = min(kl[s], key);
-                        key = max(kl[s], key);
-                        kl[s] = lo;
+                for (int u = 0; u < 4; ++u) sq[u] = sorted[p + u < p1 ? p + u : p1 - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (p + u >= p1) break;
+                    const float4 sj = sq[u];
+                    const int w = __float_as_int(sj.w);
+                    const float dx = xi - sj.x, dy = yi - sj.y, dz = zi - sj.z;
+                    float d = (dx * dx + dy * dy) + dz * dz;
+                    if (ti && (w & 0x40000000)) d = 1e10f;
+                    if ((d - thr) < 0.0f) {
+                        const unsigned qd = min((unsigned)(d * qscale), qtop);      // monotone in d (d >= 0; a NaN never gets here)
+                        unsigned key = (qd << jb) | (unsigned)(w & 0x3fffffff);
+#pragma unroll
+                        for (int s = 0; s <= K; ++s) {
+                            const unsigned lo = min(kl[s], key);
+                            key = max(kl[s], key);
+                            kl[s] = lo;
+                        }
+                        ++tot;
                     }
-                    ++tot;
                 }
             }
         }

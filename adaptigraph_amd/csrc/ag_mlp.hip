@@ -880,7 +880,19 @@ __device__ __forceinline__ void send_remap_body(const AgFwdArgs &a, int block, i
 {
     const int E = a.row_ptr[a.B * a.N];
     const bool ovf = *a.ovf != 0;                // the call overflowed the compact tables: round 0 gathers the full-size sender table by node id
-    for (int e = block * 256 + threadIdx.x; e < E; e += nblocks * 256) a.send_c[e] = ovf ? a.edge_send[e] : a.node_row[a.edge_send[e]];
+    // four edges per thread and trip with their loads batched (index, then row, then store): a plain strided loop orders every trip's two dependent
+    // loads behind the previous trip's store
+    const int stride = nblocks * 256;
+    for (int e0 = block * 256 + threadIdx.x; e0 < E; e0 += 4 * stride) {
+        int sd[4], rw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sd[u] = e0 + u * stride < E ? a.edge_send[e0 + u * stride] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rw[u] = ovf ? sd[u] : a.node_row[sd[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * stride < E) a.send_c[e0 + u * stride] = rw[u];
+    }
 }
 __global__ __launch_bounds__(256) void send_remap_kernel(AgFwdArgs a) { send_remap_body(a, blockIdx.x, gridDim.x); }
 
@@ -2232,7 +2244,7 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
-            const int nb_tab = (a.B * a.N + 255) / 256, nb_map = a.dedup ? ((a.e_cap + 255) / 256 < 2048 ? (a.e_cap + 255) / 256 : 2048) : 0;
+            const int nb_tab = (a.B * a.N + 255) / 256, nb_map = a.dedup ? ((a.e_cap + 1023) / 1024 < 4096 ? (a.e_cap + 1023) / 1024 : 4096) : 0;      // four edges per thread
             hipLaunchKernelGGL(edge_node_tab_kernel, dim3(nb_tab + nb_map), dim3(256), 0, s, a, nb_tab);
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);   // (always eight waves, whatever AG_MLP_THREADS is)
             return;
