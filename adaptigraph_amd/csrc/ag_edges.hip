@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
         G.x0 = mn[0]; G.y0 = mn[1]; G.z0 = mn[2]; G.inv = 1.0f / cs; G.nx = nx; G.ny = ny; G.nz = nz; G.total = 0;
     }
     __syncthreads();
+    if (a.connect && tid == 0) a.flag[b] = 0;        // batch_mask of this sample (set by the selection kernels, read by finalize_connect)
     const GridParams g = G;
     const int ncell = g.nx * g.ny * g.nz;
     for (int c = tid; c < ncell; c += 256) cnt[c] = 0;
@@ -571,16 +572,71 @@ __global__ __launch_bounds__(256, 4) void select_lanes_packed_kernel(AgEdgeArgs 
 // One THREAD per receiver: the kept senders are already ascending and at most top-k long, the sample's tool indices are
 // compacted once per workgroup into LDS (ascending), so a row is a two-pointer merge of two short sorted lists.
 // (A wave per receiver sweeping all N candidate senders was 45 % of the whole cloth-4k step.)
+constexpr int kKeepFast = 8;          // finalize_connect_kernel: kept-sender lists of top-k <= 8 are merged from LDS
 constexpr int kToolListMax = 8192;     // LDS-resident tool list; more tools than this take the sweep kernel below
 
 __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
 {
     extern __shared__ int tools[];
     __shared__ int wcount[4];
+    __shared__ int kept[256 * kKeepFast];           // per-thread list of the kept NON-tool senders (fast path: top-k <= kKeepFast)
     const int b = blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
+    // the tool flags of the sample, all of a thread's loads in flight together (N <= 256 * kFlagK; beyond that they are read in the loop)
+    constexpr int kFlagK = 17;
+    unsigned tflag = 0;
+    const bool flags_cached = N <= 256 * kFlagK;
+    if (flags_cached) {
+        unsigned char tv[kFlagK];
+#pragma unroll
+        for (int u = 0; u < kFlagK; ++u) tv[u] = tl[tid + 256 * u < N ? tid + 256 * u : 0];
+#pragma unroll
+        for (int u = 0; u < kFlagK; ++u) tflag |= (tid + 256 * u < N && tv[u]) ? 1u << u : 0u;
+    }
+    // this receiver's kept senders and their tool flags: two batches of loads instead of a chain of two dependent loads per sender
+    const int i = blockIdx.x * 256 + tid;
+    const size_t row = (size_t)b * N + (i < N ? i : 0);
+    const int deg0 = i < N ? a.deg[row] : 0;
+    const bool fast = a.cap0 <= kKeepFast;
+    int nkept = 0;
+    if (fast) {
+        int sv[kKeepFast];
+        unsigned char sf[kKeepFast];
+#pragma unroll
+        for (int u = 0; u < kKeepFast; ++u) sv[u] = u < deg0 ? a.sel0[row * a.cap0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kKeepFast; ++u) sf[u] = tl[sv[u]];
+#pragma unroll
+        for (int u = 0; u < kKeepFast; ++u)
+            if (u < deg0 && !sf[u]) kept[tid * kKeepFast + nkept++] = sv[u];
+    }
     int nt = 0;
-    for (int j0 = 0; j0 < N; j0 += 256) {          // ordered compaction of the sample's tool indices
+    if (flags_cached) {          // ordered compaction of the sample's tool indices with two barriers in all (the loop below: two per 256 slots)
+        __shared__ int wc[kFlagK][4], wbase[kFlagK][4], s_total;
+        unsigned long long bal[kFlagK];
+#pragma unroll
+        for (int u = 0; u < kFlagK; ++u) {
+            bal[u] = __ballot((tflag >> u & 1u) != 0);
+            if (lane == 0) wc[u][wave] = __popcll(bal[u]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int u = 0; u < kFlagK; ++u)
+                for (int w = 0; w < 4; ++w) { wbase[u][w] = run; run += wc[u][w]; }
+            s_total = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kFlagK; ++u)
+            if (tflag >> u & 1u) {
+                const int slot = wbase[u][wave] + __popcll(bal[u] & ((1ull << lane) - 1ull));
+                if (slot < a.cap) tools[slot] = tid + 256 * u;      // only the first `cap` tools can reach a (cap-long) output row
+            }
+        nt = s_total;
+        __syncthreads();
+    } else
+    for (int j0 = 0, it = 0; j0 < N; j0 += 256, ++it) {
         const int j = j0 + tid;
         const bool t = j < N && tl[j];
         const unsigned long long bal = __ballot(t);
@@ -593,17 +649,27 @@ __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
         nt += wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();
     }
-    const int i = blockIdx.x * 256 + tid;
     if (i >= N) return;
-    const size_t row = (size_t)b * N + i;
     const bool mi = mk[i], ti = tl[i];
-    const int deg0 = a.deg[row];
     const bool add_tools = mi && (a.variant == 1 ? (a.flag[b] != 0) : !ti);
     const bool keep_sel = !ti;
     const int32_t *in = a.sel0 + row * a.cap0;
     int32_t *dst = a.sel + row * a.cap;
     const int na = keep_sel ? deg0 : 0, nb = add_tools ? (nt < a.cap ? nt : a.cap) : 0;
     int ia = 0, ib = 0, out = 0;
+    if (fast) {          // both lists in LDS: the merge is a few dozen LDS reads and the row's stores
+        const int *ka = kept + tid * kKeepFast;
+        const int nk = keep_sel ? nkept : 0;
+        while (ia < nk || ib < nb) {
+            const bool take_a = ia < nk && (ib >= nb || ka[ia] < tools[ib]);
+            const int j = take_a ? ka[ia] : tools[ib];
+            if (out < a.cap) dst[out] = j;
+            ++out;
+            if (take_a) ++ia; else ++ib;
+        }
+        a.deg[row] = out < a.cap ? out : a.cap;
+        return;
+    }
     int sa = -1;
     while (ia < na) { sa = in[ia]; if (!tl[sa]) break; ++ia; }          // tool senders among the kept ones come from list B
     while (ia < na || ib < nb) {
@@ -714,9 +780,10 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
 void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
 {
     const int rows = a.B * a.N;
-    if (a.connect) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
+    // (connect_tools_all: the per-sample batch_mask word is cleared by bin_kernel on the cell path — one fill launch per step less)
     static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
     const bool cells = force < 0 ? a.N >= 256 : force != 0;
+    if (a.connect && !cells) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
     if (cells) {
         hipLaunchKernelGGL(bin_kernel, dim3(a.B), dim3(256), 0, s, a);
         const dim3 lgrid((a.N + 255) / 256, a.B);
