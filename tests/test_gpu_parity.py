@@ -117,6 +117,25 @@ def test_edges_vs_oracle_exact(material, n_obj, batch, variant, kw):
         assert np.array_equal(r, recv[b, :n_rel[b]]) and np.array_equal(s, send[b, :n_rel[b]]), f"sample {b}"
 
 
+@pytest.mark.parametrize("material,n_obj,topk,variant", [
+    ("rope", 300, 10, "batch"),          # connect_tools_all with top-k > 8: finalize_connect_kernel's generic merge (the LDS merge serves top-k <= 8)
+    ("granular", 600, 20, "single"),     # ... with five tools per sample
+    ("cloth", 4900, 5, "batch"),         # N = 4 901 > 4 352: bin_kernel and finalize_connect_kernel re-read the sample instead of caching it in registers
+    ("cloth", 4900, 5, "single"),
+])
+def test_edges_connect_tools_all_beyond_the_fast_paths_vs_oracle(material, n_obj, topk, variant):
+    """connect_tools_all = True on shapes that leave the register / LDS fast paths of the r05 edge builder (kept-sender lists longer than 8, samples
+    larger than 17 x 256 slots): the edge lists still equal the oracle's bit for bit."""
+    g = synth.make_graph_inputs(material, n_obj, 2, seed=33, **(dict(spacing=0.1) if material == "rope" else {}))
+    radius = synth.MATERIALS[material]["radius"]
+    pos = g["state"][:, -1].copy()
+    n_rel, recv, send = ago.build_edges(pos, radius, g["mask"], g["tool_mask"], topk, True, variant)
+    csr = aggraph.build_edges(t(pos), radius, t(g["mask"]), t(g["tool_mask"]), topk, True, variant, max_tools=g["n_tools"])
+    assert csr.n_rel().cpu().tolist() == n_rel.tolist()
+    for b, (r, s_) in enumerate(csr.to_lists()):
+        assert np.array_equal(r, recv[b, :n_rel[b]]) and np.array_equal(s_, send[b, :n_rel[b]]), f"sample {b}"
+
+
 @pytest.mark.parametrize("n_obj,seed", [(300, 1), (2000, 2), (5000, 3)])
 def test_edges_topk20_packed_key_boundary_vs_oracle(n_obj, seed):
     """Top-k 20 (granular) takes the packed-key selection kernel (csrc/ag_edges.hip select_lanes_packed_kernel): 32-bit keys that
