@@ -460,12 +460,18 @@ void run_node_encode_fallback(ag_model *m, AgFwdArgs &a, hipStream_t s)
     if (a.dedup) ag_launch_node_encode_fallback(m->w, a, s);
 }
 
+// does this call's edge encoder run on the weight-stationary kernel (the condition ag_launch_edge_encode tests, ag_mlp.hip)
+bool edge_ws_path(const AgFwdArgs &a)
+{
+    return a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2 && a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL;
+}
+
 void run_edge_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     // row-tile claim counter of the STREAMING edge encoders; the weight-stationary kernel (default mode) deals its blocks statically: no fill launch
-    const bool ws = a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2 && a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL;
+    const bool ws = edge_ws_path(a);
     if (a.tile_ctr && !ws) (void)hipMemsetAsync(a.tile_ctr, 0, sizeof(int), s);
-    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup && !ws) ag_launch_send_remap(a, s); }      // (ws: mapped by the node-table launch)
+    { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup && !ws && !a.remap_done) ag_launch_send_remap(a, s); }      // (ws: mapped by the node-table launch)
 }
 
 void run_propagate(ag_model *m, AgFwdArgs &a, hipStream_t s)
@@ -1125,11 +1131,26 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
     for (int ai = 1; ai <= p->n_steps && rc == AG_OK; ++ai)
         for (int k = 0; k < parts && rc == AG_OK; ++k) {
             hipStream_t s = run[k].s;
-            { Timed tm(m, AG_K_EDGES, s); ag_launch_build_edges(part[k].e, s); }
-            if (ai == 1) setup_args(m, part[k].f, part_blocks, p->n_steps);
-            if (ai == 1 || !part[k].f.dedup) run_node_encode(m, part[k].f, s);       // step-invariant when de-duplicated (see run_node_encode)
-            run_node_encode_fallback(m, part[k].f, s);
-            run_edge_encode(m, part[k].f, s);
+            AgFwdArgs &f = part[k].f;
+            AgEdgeArgs &e = part[k].e;
+            if (ai == 1) {
+                setup_args(m, f, part_blocks, p->n_steps);
+                // Riders of the edge builder's launches (AgEdgeArgs): the per-node input rows of the weight-stationary edge encoder and, for a
+                // de-duplicated node encoder, the sender column mapped to compact rows — one 15 us launch per model step less.  The map needs
+                // node_row, so the node encoder (which does not read the edges) goes in front of the first step's edge build.
+                if (edge_ws_path(f)) {
+                    e.tab_state = f.state; e.tab_attrs = f.attrs; e.tab_pinst = f.p_instance; e.tab_out = f.edge_node_tab;
+                    e.tab_n_inst = f.n_inst; e.tab_n_p = f.n_p; e.tab_status = f.status;
+                }
+                if (f.dedup) { e.map_node_row = f.node_row; e.map_ovf = f.ovf; e.map_send_c = f.send_c; }
+            }
+            if (ai == 1 || !f.dedup) run_node_encode(m, f, s);       // step-invariant when de-duplicated (see run_node_encode)
+            int riders;
+            { Timed tm(m, AG_K_EDGES, s); riders = ag_launch_build_edges(e, s); }
+            f.tab_done = (riders & AG_RIDER_TAB) != 0;
+            f.remap_done = (riders & AG_RIDER_MAP) != 0;
+            run_node_encode_fallback(m, f, s);
+            run_edge_encode(m, f, s);
             if (ai == 1 && k == 0 && parts > 1 && m->stagger) {
                 // phase offset: the other parts start once part 0 has finished its first MFMA-bound encode stage, so
                 // from then on one stream's HBM-bound segment reduce co-runs with another stream's MFMA-bound stage

@@ -107,6 +107,8 @@ struct AgFwdArgs {
     const int32_t *hr_row;           // segment reduce: row of Hr to read for node g (NULL: g) — node_row in round 0
     const float *pn_rows;            // node_update: Pn from compact rows pn_rows[node_row[g]] (NULL: packed table pn)
     const float *h_rows;             // node_update, round 0: residual h from compact rows (NULL: packed table h)
+    // set per model step by ag_rollout: the edge builder's launches of this step already produced edge_node_tab / send_c (AgEdgeArgs riders)
+    int tab_done, remap_done;
 };
 #define AG_TILE_CTRS 4
 #define AG_DEDUP_REPS 8            // distinct node-encoder input rows shared within a sample (more than that: private rows)
@@ -263,8 +265,56 @@ struct AgEdgeArgs {
     void *grid_raw;        // (B) GridParams
     int32_t *cell_start;   // (B, 8193)
     float4 *sorted;        // (B, N) x, y, z, bits(j | tool << 30) in cell order
+    // Riders (ag_rollout only; all NULL elsewhere): two pieces of the MODEL step that depend on nothing but what the builder's own launches read or
+    // write, carried by those launches instead of a launch of their own (a 15 us latency chain per model step on a nearly idle chip):
+    //  * the per-node input rows of the edge features (AgFwdArgs::edge_node_tab: a function of the state only) by extra workgroups of bin_kernel;
+    //  * the sender column mapped to compact rows (AgFwdArgs::send_c, node-encoder de-duplication) by rowptr_scatter_kernel where it writes edge_send.
+    const float *tab_state, *tab_attrs, *tab_pinst;   // (B, AG_NHIS, N, 3), (B, N, 2), (B, tab_n_p, tab_n_inst)
+    float *tab_out;                                   // (B*N, 16); NULL: no rider
+    int tab_n_inst, tab_n_p;
+    int *tab_status;                                  // the model's sticky status word (non-finite raw inputs), or NULL
+    const int32_t *map_node_row;                      // (B*N) compact row of every node
+    const int *map_ovf;                               // device flag: this call runs without de-duplication (identity map)
+    int32_t *map_send_c;                              // (E); NULL: no rider
 };
-void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);
+enum { AG_RIDER_TAB = 1, AG_RIDER_MAP = 2 };
+int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns the riders its launches carried (AG_RIDER_*)
+
+// Per-node inputs of the edge features (model.py:155-165, 220-253), 64 bytes per node, so that the weight-stationary edge encoder's gather is
+// two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].  The per-edge features are
+// then plain differences of two rows — the same subtractions in the same order as (pr[i+1] - pr[i]) - (ps[i+1] - ps[i]) in edge_features.
+// One thread per node g; shared by edge_node_tab_kernel (ag_mlp.hip) and the rider workgroups of bin_kernel (ag_edges.hip).
+__device__ __forceinline__ void ag_edge_node_tab_row(const float *state, const float *attrs, const float *p_instance, int n_inst, int n_p,
+                                                     int B, int N, float *tab, int *status, int g)
+{
+    if (g >= B * N) return;
+    const int b = g / N, i = g - b * N;
+    float p[AG_NHIS][3];
+#pragma unroll
+    for (int hh = 0; hh < AG_NHIS; ++hh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[hh][c] = state[(((size_t)b * AG_NHIS + hh) * N + i) * 3 + c];
+    float o[16];
+    o[0] = attrs[(size_t)g * 2]; o[1] = attrs[(size_t)g * 2 + 1];
+    o[2] = (n_inst > 0 && i < n_p) ? p_instance[((size_t)b * n_p + i) * n_inst] : 0.0f;
+    o[3] = 0.0f;
+#pragma unroll
+    for (int hh = 0; hh + 1 < AG_NHIS; ++hh)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[4 + hh * 3 + c] = p[hh + 1][c] - p[hh][c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[4 + (AG_NHIS - 1) * 3 + c] = p[AG_NHIS - 1][c];
+    float4 *dst = reinterpret_cast<float4 *>(tab + (size_t)g * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    // Non-finite raw inputs raise the status bit HERE: the weight-stationary kernel builds its first-layer operands without the range check the
+    // streaming kernel applies to them (h3_pair<true>), and a NaN that reaches a hidden activation with its sign bit set is ReLU'd to 0.
+    // (A finite difference beyond fp16's range becomes +-inf there and is caught by the hidden layers' own check.)
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += o[k] * 0.0f;      // 0 for finite rows, NaN otherwise
+    if (status && !(sum == 0.0f)) atomicOr(status, 1);
+}
 
 struct AgStepArgs {
     float *state;             // (B, H, N, 3) working copy, shifted in place

@@ -178,6 +178,11 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     __shared__ int cnt[kCellMax];
     __shared__ float red[6][4];
     __shared__ GridParams G;
+    if ((int)blockIdx.x >= a.B) {       // rider workgroups (ag_rollout): the model step's per-node input rows of the edge features, a function of the state only
+        ag_edge_node_tab_row(a.tab_state, a.tab_attrs, a.tab_pinst, a.tab_n_inst, a.tab_n_p, a.B, a.N, a.tab_out, a.tab_status,
+                             ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x);
+        return;
+    }
     const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *pos = a.pos + (size_t)b * a.pos_stride;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
@@ -741,6 +746,10 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
 {
     __shared__ int s_ptr[kScanRows], s_deg[kScanRows];
     const int rows = a.B * a.N;
+    // rider (ag_rollout, de-duplicated node encoder): the sender column mapped to compact rows for round 0's reduce, written where edge_send is.
+    // (The overflow word is read here, with the partial sums, not in front of the loop that uses it: one memory round trip less on the chain.)
+    const bool map = a.map_send_c != nullptr;
+    const bool ident = map && *a.map_ovf != 0;          // the call overflowed the compact tables: round 0 gathers the full-size table by node id
     int part = 0;
     for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += a.blk_sum[i];
     int base;
@@ -759,33 +768,46 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
     const int32_t *src = sel + (size_t)row0 * cap;
     const int n = nloc * cap;
     for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
-        int v[4];
+        int v[4], e[4], sg[4], rw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = i0 + 256 * u < n ? src[i0 + 256 * u] : 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = i0 + 256 * u;
-            if (idx >= n) break;
+            e[u] = -1; sg[u] = 0;
+            if (idx >= n) continue;
             const int lr = idx / cap, slot = idx - lr * cap;
             if (slot >= s_deg[lr]) continue;
-            const int row = row0 + lr, e = s_ptr[lr] + slot;
-            a.edge_recv[e] = row;
-            a.edge_send[e] = (row / a.N) * a.N + v[u];
+            const int row = row0 + lr;
+            e[u] = s_ptr[lr] + slot;
+            sg[u] = (row / a.N) * a.N + v[u];
+            a.edge_recv[e[u]] = row;
+            a.edge_send[e[u]] = sg[u];
+        }
+        if (map) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rw[u] = ident ? sg[u] : a.map_node_row[sg[u]];      // (slot 0 of an unused lane: row 0, in range, not stored)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e[u] >= 0) a.map_send_c[e[u]] = rw[u];
         }
     }
 }
 
 }  // namespace
 
-void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
+int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
 {
     const int rows = a.B * a.N;
+    int riders = 0;
     // (connect_tools_all: the per-sample batch_mask word is cleared by bin_kernel on the cell path — one fill launch per step less)
     static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
     const bool cells = force < 0 ? a.N >= 256 : force != 0;
     if (a.connect && !cells) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
     if (cells) {
-        hipLaunchKernelGGL(bin_kernel, dim3(a.B), dim3(256), 0, s, a);
+        const int nb_tab = a.tab_out ? (rows + 255) / 256 : 0;        // rider workgroups follow the B binning ones
+        hipLaunchKernelGGL(bin_kernel, dim3(a.B + nb_tab), dim3(256), 0, s, a);
+        if (nb_tab) riders |= AG_RIDER_TAB;
         const dim3 lgrid((a.N + 255) / 256, a.B);
         static const int packed = getenv("AG_EDGE_PACKED") ? atoi(getenv("AG_EDGE_PACKED")) : 1;      // 0: the exact (d, j) network for every receiver
         int jb = 1;
@@ -820,4 +842,6 @@ void ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     const int nblk = (rows + kScanRows - 1) / kScanRows;
     hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(rowptr_scatter_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
+    if (a.map_send_c) riders |= AG_RIDER_MAP;
+    return riders;
 }

@@ -1293,43 +1293,14 @@ __device__ __forceinline__ void ws_q16_chore(const f32x16 &acc, WsQ16 &Q, unsign
 // drains vmcnt, i.e. it would wait at every round for the Eterm stores (and gather loads) issued a few hundred cycles earlier.
 __device__ __forceinline__ void ws_round_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Per-node inputs of the edge features (model.py:155-165, 220-253), 64 bytes per node, so that the weight-stationary kernel's
-// gather is two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].
-// The per-edge features are then plain differences of two rows — the same subtractions in the same order as
-// (pr[i+1] - pr[i]) - (ps[i+1] - ps[i]) in edge_features.
+// Per-node inputs of the edge features: ag_edge_node_tab_row (ag_common.h), one thread per node.
 // Workgroups past the node range (de-duplicated calls) map the sender column to compact rows for round 0's reduce (send_remap_body): one small
-// launch per model step instead of two.
+// launch per model step instead of two.  (In ag_rollout both ride the edge builder's launches instead — AgEdgeArgs riders — and this kernel is
+// launched for what they did not cover: ag_forward, the brute-force edge path, the CU-partitioned rollout.)
 __global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a, int nb_tab)
 {
     if ((int)blockIdx.x >= nb_tab) { send_remap_body(a, (int)blockIdx.x - nb_tab, (int)gridDim.x - nb_tab); return; }
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.B * a.N) return;
-    const int b = g / a.N, i = g - b * a.N;
-    float p[AG_NHIS][3];
-#pragma unroll
-    for (int hh = 0; hh < AG_NHIS; ++hh)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[hh][c] = a.state[(((size_t)b * AG_NHIS + hh) * a.N + i) * 3 + c];
-    float o[16];
-    o[0] = a.attrs[(size_t)g * 2]; o[1] = a.attrs[(size_t)g * 2 + 1];
-    o[2] = (a.n_inst > 0 && i < a.n_p) ? a.p_instance[((size_t)b * a.n_p + i) * a.n_inst] : 0.0f;
-    o[3] = 0.0f;
-#pragma unroll
-    for (int hh = 0; hh + 1 < AG_NHIS; ++hh)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o[4 + hh * 3 + c] = p[hh + 1][c] - p[hh][c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[4 + (AG_NHIS - 1) * 3 + c] = p[AG_NHIS - 1][c];
-    float4 *dst = reinterpret_cast<float4 *>(a.edge_node_tab + (size_t)g * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-    // Non-finite raw inputs raise the status bit HERE: the weight-stationary kernel builds its first-layer operands without the range check the
-    // streaming kernel applies to them (h3_pair<true>), and a NaN that reaches a hidden activation with its sign bit set is ReLU'd to 0.
-    // (A finite difference beyond fp16's range becomes +-inf there and is caught by the hidden layers' own check.)
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sum += o[k] * 0.0f;      // 0 for finite rows, NaN otherwise
-    if (a.status && !(sum == 0.0f)) atomicOr(a.status, 1);
+    ag_edge_node_tab_row(a.state, a.attrs, a.p_instance, a.n_inst, a.n_p, a.B, a.N, a.edge_node_tab, a.status, blockIdx.x * 256 + threadIdx.x);
 }
 
 // First layer of one 32-edge block for out-tiles [T0, T0 + NT): per tile 2 k16-steps x (lo, hi) fp16 MFMAs with the A fragments read from the
@@ -2244,8 +2215,9 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
             const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
-            const int nb_tab = (a.B * a.N + 255) / 256, nb_map = a.dedup ? ((a.e_cap + 1023) / 1024 < 4096 ? (a.e_cap + 1023) / 1024 : 4096) : 0;      // four edges per thread
-            hipLaunchKernelGGL(edge_node_tab_kernel, dim3(nb_tab + nb_map), dim3(256), 0, s, a, nb_tab);
+            const int nb_tab = a.tab_done ? 0 : (a.B * a.N + 255) / 256;
+            const int nb_map = a.dedup && !a.remap_done ? ((a.e_cap + 1023) / 1024 < 4096 ? (a.e_cap + 1023) / 1024 : 4096) : 0;      // four edges per thread
+            if (nb_tab + nb_map > 0) hipLaunchKernelGGL(edge_node_tab_kernel, dim3(nb_tab + nb_map), dim3(256), 0, s, a, nb_tab);
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);   // (always eight waves, whatever AG_MLP_THREADS is)
             return;
         }
