@@ -1144,15 +1144,6 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
                 }
                 if (f.dedup) { e.map_node_row = f.node_row; e.map_ovf = f.ovf; e.map_send_c = f.send_c; }
             }
-            // ... and the state update of the previous step (rollout_step's work) by the binning workgroups of this step's edge build, where the
-            // builder supports it (cell path, N <= 2 048, n_his 4): the last step's update keeps its own launch
-            const bool fuse_step = H == AG_NHIS && ag_edges_fuses_step(e);
-            if (fuse_step && ai > 1) {
-                const AgStepArgs &st = run[k].st;
-                e.step_state = st.state; e.step_delta = st.delta; e.step_pred = st.pred_pos; e.step_obj_mask = st.obj_mask;
-                e.step_repeat = st.repeat; e.step_out_seq = st.out_seq; e.step_n_p = st.n_p; e.step_no = ai - 1;
-                e.step_height_mode = st.height_mode; e.step_raise = st.raise;
-            }
             if (ai == 1 || !f.dedup) run_node_encode(m, f, s);       // step-invariant when de-duplicated (see run_node_encode)
             int riders;
             { Timed tm(m, AG_K_EDGES, s); riders = ag_launch_build_edges(e, s); }
@@ -1170,7 +1161,7 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
             }
             run_propagate(m, part[k].f, s);
             run[k].st.step = ai;
-            if (!fuse_step || ai == p->n_steps) { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(run[k].st, s); }
+            { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(run[k].st, s); }
         }
     for (int k = 0; k < parts && rc == AG_OK && state_final; ++k) {
         const size_t b0 = (size_t)part[k].b0;

@@ -276,20 +276,9 @@ struct AgEdgeArgs {
     const int32_t *map_node_row;                      // (B*N) compact row of every node
     const int *map_ovf;                               // device flag: this call runs without de-duplication (identity map)
     int32_t *map_send_c;                              // (E); NULL: no rider
-    //  * the state update of the PREVIOUS model step (rollout_step_kernel's work, AgStepArgs below: same fields) by bin_kernel's workgroup of
-    //    the sample, which then bins the positions it has just formed (and writes the sample's tab rows itself: no rider workgroups);
-    //    only where ag_edges_fuses_step() says so.
-    float *step_state;                                // (B, AG_NHIS, N, 3) shifted in place; NULL: no rider
-    const float *step_delta, *step_pred;              // (B, N, 3), (B, step_n_p, 3)
-    const uint8_t *step_obj_mask;                     // (B, step_n_p) or NULL (height mode 1)
-    const int32_t *step_repeat;                       // (B)
-    float *step_out_seq;                              // (B, step_n_p, 3)
-    int step_n_p, step_no, step_height_mode;
-    float step_raise;
 };
-enum { AG_RIDER_TAB = 1, AG_RIDER_MAP = 2, AG_RIDER_STEP = 4 };
+enum { AG_RIDER_TAB = 1, AG_RIDER_MAP = 2 };
 int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns the riders its launches carried (AG_RIDER_*)
-int ag_edges_fuses_step(const AgEdgeArgs &a);                       // 1: a build with step_state set performs the state update (else the caller launches rollout_step)
 
 // Per-node inputs of the edge features (model.py:155-165, 220-253), 64 bytes per node, so that the weight-stationary edge encoder's gather is
 // two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].  The per-edge features are

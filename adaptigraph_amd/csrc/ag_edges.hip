@@ -173,125 +173,11 @@ __device__ __forceinline__ int cell_coord(float x, float x0, float inv, int n)
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 
-// bin_kernel's rider (ag_rollout): the state update of the previous model step for sample b — rollout_step_kernel's arithmetic (ag_rollout.hip;
-// forward_dynamics.py:160-176 / :356-372) in bin_kernel's particle-per-thread layout (particle j = tid + 256 i: the same per-thread order of the
-// height reduction as `for (i = tid; i < n_p; i += 256)` there, so the same bits), then the sample's rows of the edge-feature node table from the
-// frames it holds, and the new positions handed to the binning passes in registers: one launch and one read of the state less per model step.
-constexpr int kStepK = 8;            // particles per thread: N <= 2 048 (72 registers of history in flight)
-
-__device__ __forceinline__ void bin_pre_step(const AgEdgeArgs &a, int b, float *sred, float (&px)[17], float (&py)[17], float (&pz)[17])
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = a.N, n_p = a.step_n_p, plane = N * 3;
-    const float *pred = a.step_pred + (size_t)b * n_p * 3;
-    float prd[kStepK][3];
-#pragma unroll
-    for (int i = 0; i < kStepK; ++i) {
-        const int j = tid + 256 * i, jc = j < n_p ? j : 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) prd[i][c] = pred[jc * 3 + c];
-    }
-    float *st = a.step_state + (size_t)b * AG_NHIS * plane;
-    const float *dl = a.step_delta + (size_t)b * plane;
-    float f[kStepK][AG_NHIS][3], dlt[kStepK][3];          // frames 1 .. H-1 of the old state land in f[.][0 .. H-2]
-#pragma unroll
-    for (int i = 0; i < kStepK; ++i) {
-        const int j = tid + 256 * i, jc = j < N ? j : 0;
-#pragma unroll
-        for (int h = 1; h < AG_NHIS; ++h)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) f[i][h - 1][c] = st[(size_t)h * plane + jc * 3 + c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dlt[i][c] = dl[jc * 3 + c];
-    }
-    float y;
-    if (a.step_height_mode == 0) {
-        float m = INFINITY;
-#pragma unroll
-        for (int i = 0; i < kStepK; ++i)
-            if (tid + 256 * i < n_p) m = fminf(m, prd[i][1]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-        if (lane == 0) sred[wave] = m;
-        __syncthreads();
-        y = fminf(fminf(sred[0], sred[1]), fminf(sred[2], sred[3]));
-    } else {
-        const uint8_t *om = a.step_obj_mask + (size_t)b * n_p;
-        float s = 0.f, cn = 0.f;
-#pragma unroll
-        for (int i = 0; i < kStepK; ++i)
-            if (tid + 256 * i < n_p) {
-                const float w = om[tid + 256 * i] ? 1.f : 0.f;
-                s += prd[i][1] * w;
-                cn += w;
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); cn += __shfl_xor(cn, o); }
-        if (lane == 0) { sred[wave] = s; sred[4 + wave] = cn; }
-        __syncthreads();
-        y = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / ((sred[4] + sred[5]) + (sred[6] + sred[7]));
-    }
-    y += a.step_raise;
-    const bool record = a.step_repeat[b] == a.step_no;
-    float *oseq = a.step_out_seq + (size_t)b * n_p * 3;
-#pragma unroll
-    for (int i = 0; i < kStepK; ++i) {
-        const int j = tid + 256 * i;
-        if (j >= N) { px[i] = py[i] = pz[i] = 0.f; continue; }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float last = f[i][AG_NHIS - 2][c];
-            f[i][AG_NHIS - 1][c] = j < n_p ? prd[i][c] : (c == 1 ? y : last + dlt[i][c]);
-        }
-#pragma unroll
-        for (int h = 0; h < AG_NHIS; ++h)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) st[(size_t)h * plane + j * 3 + c] = f[i][h][c];
-        if (record && j < n_p) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) oseq[j * 3 + c] = prd[i][c];
-        }
-        px[i] = f[i][AG_NHIS - 1][0]; py[i] = f[i][AG_NHIS - 1][1]; pz[i] = f[i][AG_NHIS - 1][2];
-    }
-#pragma unroll
-    for (int i = kStepK; i < 17; ++i) px[i] = py[i] = pz[i] = 0.f;
-    if (a.tab_out) {         // ag_edge_node_tab_row (ag_common.h) from the frames in registers: the same subtractions
-        float at[kStepK][3];
-#pragma unroll
-        for (int i = 0; i < kStepK; ++i) {
-            const int j = tid + 256 * i, jc = j < N ? j : 0;
-            const size_t g = (size_t)b * N + jc;
-            at[i][0] = a.tab_attrs[g * 2]; at[i][1] = a.tab_attrs[g * 2 + 1];
-            at[i][2] = (a.tab_n_inst > 0 && jc < a.tab_n_p) ? a.tab_pinst[((size_t)b * a.tab_n_p + jc) * a.tab_n_inst] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < kStepK; ++i) {
-            const int j = tid + 256 * i;
-            if (j >= N) continue;
-            float o[16];
-            o[0] = at[i][0]; o[1] = at[i][1]; o[2] = at[i][2]; o[3] = 0.0f;
-#pragma unroll
-            for (int hh = 0; hh + 1 < AG_NHIS; ++hh)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) o[4 + hh * 3 + c] = f[i][hh + 1][c] - f[i][hh][c];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[4 + (AG_NHIS - 1) * 3 + c] = f[i][AG_NHIS - 1][c];
-            float4 *dst = reinterpret_cast<float4 *>(a.tab_out + ((size_t)b * N + j) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += o[k] * 0.0f;      // 0 for finite rows, NaN otherwise
-            if (a.tab_status && !(sum == 0.0f)) atomicOr(a.tab_status, 1);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
 {
     __shared__ int cnt[kCellMax];
     __shared__ float red[6][4];
     __shared__ GridParams G;
-    __shared__ float sred[8];
     if ((int)blockIdx.x >= a.B) {       // rider workgroups (ag_rollout): the model step's per-node input rows of the edge features, a function of the state only
         ag_edge_node_tab_row(a.tab_state, a.tab_attrs, a.tab_pinst, a.tab_n_inst, a.tab_n_p, a.B, a.N, a.tab_out, a.tab_status,
                              ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x);
@@ -308,19 +194,11 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     unsigned vbits = 0, tbits = 0;
     if (cached) {
         unsigned char mv[kBinK], tv[kBinK];
-        const bool pre = a.step_state != nullptr;      // (host: only with N <= 256 * kStepK)
 #pragma unroll
         for (int i = 0; i < kBinK; ++i) {
             const int j = tid + 256 * i, jc = j < N ? j : 0;
             mv[i] = mk[jc]; tv[i] = tl[jc];
-        }
-        if (pre) bin_pre_step(a, b, sred, px, py, pz);
-        else {
-#pragma unroll
-            for (int i = 0; i < kBinK; ++i) {
-                const int j = tid + 256 * i, jc = j < N ? j : 0;
-                px[i] = pos[jc * 3]; py[i] = pos[jc * 3 + 1]; pz[i] = pos[jc * 3 + 2];
-            }
+            px[i] = pos[jc * 3]; py[i] = pos[jc * 3 + 1]; pz[i] = pos[jc * 3 + 2];
         }
 #pragma unroll
         for (int i = 0; i < kBinK; ++i) {
@@ -918,33 +796,18 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
 
 }  // namespace
 
-static bool use_cells(const AgEdgeArgs &a)
-{
-    static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
-    return force < 0 ? a.N >= 256 : force != 0;
-}
-
-int ag_edges_fuses_step(const AgEdgeArgs &a)
-{
-    static const int off = getenv("AG_NO_STEP_FUSION") ? atoi(getenv("AG_NO_STEP_FUSION")) : 0;
-    return !off && use_cells(a) && a.N <= 256 * kStepK;
-}
-
 int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
 {
     const int rows = a.B * a.N;
     int riders = 0;
     // (connect_tools_all: the per-sample batch_mask word is cleared by bin_kernel on the cell path — one fill launch per step less)
-    const bool cells = use_cells(a);
+    static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
+    const bool cells = force < 0 ? a.N >= 256 : force != 0;
     if (a.connect && !cells) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
     if (cells) {
-        AgEdgeArgs ab = a;
-        if (ab.step_state && !ag_edges_fuses_step(a)) ab.step_state = nullptr;      // (a caller that tested the predicate never gets here)
-        const bool pre = ab.step_state != nullptr;
-        const int nb_tab = a.tab_out && !pre ? (rows + 255) / 256 : 0;        // rider workgroups follow the B binning ones (pre-step: each writes its sample's rows)
-        hipLaunchKernelGGL(bin_kernel, dim3(a.B + nb_tab), dim3(256), 0, s, ab);
-        if (a.tab_out) riders |= AG_RIDER_TAB;
-        if (pre) riders |= AG_RIDER_STEP;
+        const int nb_tab = a.tab_out ? (rows + 255) / 256 : 0;        // rider workgroups follow the B binning ones
+        hipLaunchKernelGGL(bin_kernel, dim3(a.B + nb_tab), dim3(256), 0, s, a);
+        if (nb_tab) riders |= AG_RIDER_TAB;
         const dim3 lgrid((a.N + 255) / 256, a.B);
         static const int packed = getenv("AG_EDGE_PACKED") ? atoi(getenv("AG_EDGE_PACKED")) : 1;      // 0: the exact (d, j) network for every receiver
         int jb = 1;
