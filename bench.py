@@ -281,7 +281,7 @@ class Engine:
             achieved = FLOP_PER_EDGE * e_per / avg_s / 1e12           # algorithmic (F_min) FLOP only
             traffic, src = pmc_traffic(self.material, batch, precision, "edge_encode")
             kname = {"f32": "edge_encode_kernel<PrecF32>", "bf16x3": "edge_encode_kernel<PrecB3>",
-                     "fast": "edge_encode_ws_kernel (+ edge_node_tab_kernel)"}[precision]
+                     "fast": "edge_encode_ws_kernel"}[precision]       # (its per-node input rows ride the edge builder's launches since r05: class build_edges)
             roof = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
                     "mfma_issue_util": EDGE_PRODUCTS[precision] * achieved / peak,
