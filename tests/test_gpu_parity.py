@@ -744,6 +744,25 @@ def test_strict_status_raises_in_the_call_that_caused_it(weights, monkeypatch):
         assert any("non-finite" in str(x.message) for x in rec)
 
 
+@pytest.mark.parametrize("n_obj", [100, 300])
+def test_nonfinite_state_raises_the_status_through_the_rollouts_riders(weights, n_obj):
+    """In ag_rollout the per-node input rows of the edge features are written by rider workgroups of the edge builder's bin_kernel (uniform-grid
+    path, N >= 256) instead of edge_node_tab_kernel (brute-force path: still that kernel): the check of the raw inputs travels with them, so a
+    non-finite position raises status bit 0 on either path, and a clean call raises nothing."""
+    import warnings as w
+    state, act = synth.make_mpc_inputs("rope", n_obj, 4, seed=3, len_lo=2, len_hi=3.9, spacing=0.1)
+    m = make_model(weights, prec="fast")
+    m.take_status()
+    out = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"]
+    assert m.take_status() == 0 and torch.isfinite(out).all()
+    bad = state.copy()
+    bad[n_obj // 2, 1] = np.float32(np.nan)
+    with w.catch_warnings():
+        w.simplefilter("ignore")
+        dynamics(t(bad), t(act), m, DEV, _ppm("rope"))
+        assert m.take_status() & 1
+
+
 @pytest.mark.parametrize("split", [32, 96, 224])
 def test_cu_partitioned_rollout_is_bitwise_the_shared_chip_rollout(weights, split):
     """ag_set_option("cu_split", X): the edge encoder on X / 8 CUs of every XCD, everything else on the other CUs, two CU-masked queues with
