@@ -22,6 +22,24 @@ def test_decode_action_matches_reference(name):
     assert np.abs(d.numpy() - g["decoded"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("n_t,grip", [(1, False), (1, True), (5, False), (5, True)])
+def test_lean_tool_placement_is_bitwise_the_reference_shaped_one(n_t, grip):
+    """dynamics() builds the tool key-points and the per-step motion with _place_tool_lean (one stack each instead of fills and slice
+    assignments); dynamics_masked() and the goldens' generator-shaped _place_tool (forward_dynamics.py:42-81) must see the same bits —
+    including the sign of zero and non-finite inputs in key-point 0."""
+    from adaptigraph_amd import forward_dynamics as fd
+    task = {"pusher_points": [[0.0, 0.0]] + [[0.0, 0.013 * i * (-1) ** i] for i in range(1, n_t)], "sim_real_ratio": 10.0, "gripper_enable": grip}
+    g = torch.Generator().manual_seed(5)
+    action = torch.rand((9, 1, 4), generator=g) * 6 - 3
+    action[0, 0, 0], action[1, 0, 1] = -0.0, float("inf")
+    decoded, _ = decode_action(action, push_length=0.1)
+    y = torch.randn(9, generator=g)
+    eef, dlt, up = fd._place_tool(task, decoded[:, 0], action[:, 0, 2], y, "cpu")
+    eef2, dlt2, up2 = fd._place_tool_lean(task, decoded[:, 0], action[:, 0, 2], y, "cpu")
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.expand_as(a).contiguous().view(torch.int32))      # noqa: E731  (bit patterns: -0.0, NaN)
+    assert up == up2 and same(eef, eef2) and same(dlt, dlt2)
+
+
 def test_threshold_rounding_per_variant():
     dev = torch.device("cpu")
     # 0.4: fp32(0.4)^2 and fp32(0.4^2 in double) differ by one ulp (SURVEY.md §5)
