@@ -89,7 +89,7 @@ def _place_tool(task, decoded, theta, y, device):
     return eef, dlt, raise_by
 
 
-def _place_tool_lean(task, decoded, theta, y, device):
+def _place_tool_lean(task, decoded, theta, y, device, zero=None):
     """_place_tool with the same values in fewer launches (dynamics() issues this set-up once per look-ahead step in front of every rollout:
     a dozen 4-us fills and slice assignments are 0.4 % of a 256 x 10 pass and more of an MPPI chunk): the key-point table is assembled by ONE
     stack, the per-step motion by one subtraction + one stack; every element is produced by the same fp32 operation as in _place_tool
@@ -99,7 +99,7 @@ def _place_tool_lean(task, decoded, theta, y, device):
     n_t = len(pts)
     raise_by = 0.01 * ratio if task["gripper_enable"] else 0.0
     d = decoded[:, 2:4] - decoded[:, 0:2]
-    dlt = torch.stack([d[:, 0], torch.zeros_like(d[:, 0]), d[:, 1]], dim=-1)[:, None].expand(-1, n_t, -1)
+    dlt = torch.stack([d[:, 0], torch.zeros_like(d[:, 0]) if zero is None else zero, d[:, 1]], dim=-1)[:, None].expand(-1, n_t, -1)      # (`zero`: a cached (bsz,) zero column)
     yy = y + raise_by if raise_by else y
     if n_t == 1:
         eef = torch.stack([decoded[:, 0], yy, decoded[:, 1]], dim=-1)[:, None]
@@ -176,7 +176,8 @@ def _constants(bsz, n_obj, n_t, max_n, device):
     mask = torch.ones((bsz, N), dtype=torch.bool, device=device)
     tool_mask = torch.zeros((bsz, N), dtype=torch.bool, device=device)
     tool_mask[:, n_obj:] = True
-    c = (attrs, p_instance, mask, tool_mask)
+    zeros = torch.zeros((1, n_obj, 3), device=device)        # expanded per call: the object particles' per-step motion (forward_dynamics.py:116-123) and a zero per sample
+    c = (attrs, p_instance, mask, tool_mask, zeros)
     nbytes = lambda e: sum(t.numel() * t.element_size() for t in e)      # noqa: E731
     while _CONST and (len(_CONST) >= _CONST_MAX or sum(map(nbytes, _CONST.values())) + nbytes(c) > _CONST_MAX_BYTES):
         _CONST.popitem(last=False)
@@ -195,7 +196,8 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     n_obj, n_t = state.shape[0], ppm_optimizer.eef_num
     N = n_obj + n_t
 
-    attrs, p_instance, mask, tool_mask = _constants(bsz, n_obj, n_t, task["max_n"], device)
+    attrs, p_instance, mask, tool_mask, obj_still = _constants(bsz, n_obj, n_t, task["max_n"], device)
+    obj_still = obj_still.expand(bsz, n_obj, 3)
     phys = _physics(ppm_optimizer, physics_param, bsz, device)
     thr = threshold_sq(ppm_optimizer.adj_thresh, bsz, torch.device(device), _lib.AG_VARIANT_BATCH)
     rep_max = repeat.max(dim=0).values
@@ -205,12 +207,11 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None):
     def prepare(li, obj, shared=False):        # tool key-points, history frames and per-step tool motion of look-ahead step li
         # (`shared`: every sample starts from the same cloud — its height is one reduction over n_obj values, not bsz of them: 28 -> 5 us at 256 x 1 000)
         y = obj[0, :, 1].min().expand(bsz) if shared else obj[:, :, 1].min(dim=1).values
-        eef, dlt, raise_by = _place_tool_lean(task, decoded[:, li], action[:, li, 2], y, device)
+        eef, dlt, raise_by = _place_tool_lean(task, decoded[:, li], action[:, li, 2], y, device, zero=obj_still[:, 0, 0])
         state0 = torch.cat([obj[:, None].expand(bsz, n_his, n_obj, 3), eef[:, None].expand(bsz, n_his, n_t, 3)], dim=2)
         delta = torch.cat([obj_still, dlt], dim=1)
         return state0, delta, raise_by
 
-    obj_still = attrs.new_zeros((1, n_obj, 3)).expand(bsz, n_obj, 3)      # the object particles' "action" is zero (forward_dynamics.py:116-123)
     # everything the first look-ahead step needs is enqueued BEFORE the call's one host sync, so that after it only the rollout's own launches
     # stand between the host and a busy GPU
     ready = prepare(0, state[None].expand(bsz, n_obj, 3), shared=True)
