@@ -15,7 +15,7 @@ EXPORTS = ("ag_last_error", "ag_version", "ag_model_create", "ag_model_update_we
            "ag_edge_capacity", "ag_edges_workspace_bytes", "ag_build_edges", "ag_forward_workspace_bytes",
            "ag_forward", "ag_rollout_workspace_bytes", "ag_rollout", "ag_profile_enable", "ag_profile_read", "ag_set_option", "ag_chamfer", "ag_chamfer_masked", "ag_gather_rows", "ag_segment_sum",
            "ag_message_forward", "ag_message_backward", "ag_model_status", "ag_train_pack", "ag_train_chain", "ag_train_weight_grads", "ag_train_weight_grads_workspace_bytes", "ag_add3_relu", "ag_relu_mask", "ag_train_weight_grads_into", "ag_edge_inputs_forward", "ag_edge_inputs_backward",
-           "ag_forward_workspace_bytes_for", "ag_rollout_workspace_bytes_for", "ag_rollout_streams_for")
+           "ag_forward_workspace_bytes_for", "ag_rollout_workspace_bytes_for", "ag_rollout_streams_for", "ag_get_option")
 KERNEL_CLASSES = ("build_edges", "node_encode", "edge_encode", "aggregate", "node_update", "rollout_step")
 
 AG_VARIANT_SINGLE, AG_VARIANT_BATCH = 0, 1
@@ -135,6 +135,8 @@ def lib():
     L.ag_model_status.argtypes = [c_void_p, ctypes.POINTER(c_int), c_void_p]
     L.ag_set_option.restype = c_int
     L.ag_set_option.argtypes = [c_void_p, ctypes.c_char_p, c_int]
+    L.ag_get_option.restype = c_int
+    L.ag_get_option.argtypes = [c_void_p, ctypes.c_char_p, ctypes.POINTER(c_int)]
     L.ag_profile_enable.restype = c_int
     L.ag_profile_enable.argtypes = [c_void_p, c_int]
     L.ag_profile_read.restype = c_int

@@ -32,23 +32,25 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     const int slot = tid / 40, c = tid - slot * 40;
     const int g = logical * kNodesPerBlock + slot;
     if (g >= a.B * a.N) return;
-    const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
+    const AgSelfView sv = ag_self_view(a, g);      // (an elided self-loop is a virtual edge: ag_common.h)
+    const int n = sv.n;
     constexpr int kFly = 4;   // edges in flight per lane, sender indices fetched one iteration ahead (see aggregate_half_kernel)
+    const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;
+    auto sender = [&](int j) { return j < n ? (j == sv.kself ? (int)gr : a.edge_send[sv.row(j)]) : -1; };
     int s[kFly];
 #pragma unroll
-    for (int i = 0; i < kFly; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
-    const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;
+    for (int i = 0; i < kFly; ++i) s[i] = sender(i);
     const float4 hr = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + 4 * c);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0; e < e1; e += kFly) {
+    for (int e = 0; e < n; e += kFly) {
         int sn[kFly];
 #pragma unroll
-        for (int i = 0; i < kFly; ++i) sn[i] = e + kFly + i < e1 ? a.edge_send[e + kFly + i] : -1;
+        for (int i = 0; i < kFly; ++i) sn[i] = sender(e + kFly + i);
         float4 t[kFly], u[kFly];
 #pragma unroll
         for (int i = 0; i < kFly; ++i)
             if (s[i] >= 0) {
-                t[i] = ag_ld_nt(reinterpret_cast<const float4 *>(a.eterm + (size_t)(e + i) * AG_FP + 4 * c));
+                t[i] = ag_ld_nt(reinterpret_cast<const float4 *>(a.eterm + (size_t)sv.row(e + i) * AG_FP + 4 * c));
                 u[i] = *reinterpret_cast<const float4 *>(a.hs + (size_t)s[i] * AG_FP + 4 * c);
             }
 #pragma unroll

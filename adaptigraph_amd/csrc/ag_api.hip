@@ -242,6 +242,9 @@ struct ag_model {
     int node_ws = 1;            // split-bf16 node_update of the rounds before the last on the weight-stationary kernel (default; env AG_NODE_WS /
                                 // "node_stationary" 0 = the streaming kernel); bit-identical
     int edge_ws = 1;            // fp16 edge stack (PrecH3) on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
+    int self_edges = 1;         // ag_rollout: leave the self-loops of attribute classes (1, 0) / (0, 1) out of the per-edge pipeline — one table row per class, added by
+                                // the segment reduce at the self-loop's position (AgFwdArgs::self_info; env AG_SELF_EDGES / "self_edges" 0 = every edge through
+                                // the pipeline); bit-identical
     int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
                                 // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
@@ -344,7 +347,7 @@ FwdLayout fwd_layout(int B, int N, int64_t e_cap)
 {
     FwdLayout L;
     L.rows_pad = align_up((size_t)B * N, AG_ROWS_PER_BLOCK);
-    L.e_pad = align_up((size_t)(e_cap > 0 ? e_cap : 1), 256);   // whole row tiles of either edge encoder (128 / 256 edges)
+    L.e_pad = ag_edge_rows_pad(e_cap);   // whole row tiles of either edge encoder (128 / 256 edges), incl. the class rows of elided self-loops
     // compact rows of the de-duplicated node encoder: AG_DEDUP_REPS shared rows per sample + a bounded private budget (the reference's drivers
     // use 2 rows per sample; until r04 this was sized for "every node private": 4 x B (N + 8) rows, 10.7 GB at the planner's 20 000 x 200)
     L.rows_c = align_up((size_t)B * AG_DEDUP_REPS + std::max<size_t>((size_t)B * N / 16, 1024), AG_ROWS_PER_BLOCK);
@@ -374,7 +377,8 @@ void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap, bool et
     // per-edge table: fp32 rows (640 B), or — sized for a model in precision mode 2 (ag_*_workspace_bytes_for) — q16 rows (320 B) + the
     // weight-stationary kernel's dump rows behind them
     a.eterm = eterm16 ? c.take<float>((L.e_pad + 256) * (AG_FP / 2)) : c.take<float>(L.e_pad * AG_FP);
-    a.edge_node_tab = c.take<float>(L.rows_pad * 16);
+    a.edge_node_tab = c.take<float>((L.rows_pad + AG_SELF_ROWS) * 16);      // + the class rows of elided self-loops (ag_edge_node_tab_row)
+    a.self_class_row0 = (int)L.rows_pad;
     a.tile_ctr = c.take<int>(AG_TILE_CTRS);
     a.enc_count = a.tile_ctr + 1;                                // (zeroed by run_node_encode before the classification fills the work list)
     a.priv_count = a.tile_ctr + 2;
@@ -549,6 +553,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
+    if (const char *v = getenv("AG_SELF_EDGES")) m->self_edges = atoi(v) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -800,12 +805,30 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "node_stationary")) m->node_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "self_edges")) m->self_edges = value != 0;
     else if (!strcmp(name, "cu_split")) {
         if (value != 0 && (value < 8 || value > m->n_cus - 8 || (value & 7)))
             return fail(AG_ERR_ARG, "ag_set_option: cu_split takes 0 (off) or a multiple of 8 in [8, %d], not %d", m->n_cus - 8, value);
         m->cu_split = value;
     }
     else return fail(AG_ERR_ARG, "ag_set_option: unknown option '%s'", name);
+    return AG_OK;
+}
+
+int ag_get_option(const ag_model *m, const char *name, int *value)
+{
+    if (!m || !name || !value) return fail(AG_ERR_ARG, "ag_get_option: null argument");
+    if (!strcmp(name, "rollout_streams")) *value = m->split;
+    else if (!strcmp(name, "fuse_aggregate")) *value = m->fuse_agg;
+    else if (!strcmp(name, "precision")) *value = m->precision == AG_PREC_F32 ? 0 : (m->eterm_half ? 2 : 1);
+    else if (!strcmp(name, "max_blocks")) *value = m->max_blocks;
+    else if (!strcmp(name, "edge_products")) *value = m->edge_products;
+    else if (!strcmp(name, "edge_stationary")) *value = m->edge_ws;
+    else if (!strcmp(name, "node_stationary")) *value = m->node_ws;
+    else if (!strcmp(name, "node_dedup")) *value = m->node_dedup;
+    else if (!strcmp(name, "self_edges")) *value = m->self_edges;
+    else if (!strcmp(name, "cu_split")) *value = m->cu_split;
+    else return fail(AG_ERR_ARG, "ag_get_option: unknown option '%s'", name);
     return AG_OK;
 }
 
@@ -940,8 +963,10 @@ static void carve_rollout(Carver &c, const ag_rollout_params *p, int B, AgFwdArg
     *pred_pos = c.take<float>((size_t)B * p->n_p * 3 + 4);
     *pred_motion = c.take<float>((size_t)B * p->n_p * 3 + 4);
     e.row_ptr = c.take<int32_t>(rows + 1);
-    e.edge_recv = c.take<int32_t>((size_t)e_cap + 1);
-    e.edge_send = c.take<int32_t>((size_t)e_cap + 1);
+    e.edge_recv = c.take<int32_t>((size_t)e_cap + 1 + AG_SELF_ROWS);      // (+ the synthetic class edges behind the list: self-edge elision)
+    e.edge_send = c.take<int32_t>((size_t)e_cap + 1 + AG_SELF_ROWS);
+    e.self_info = c.take<int32_t>(rows);
+    e.self_pos = c.take<int32_t>(rows);
     e.B = B; e.N = p->N; e.connect = p->connect_tools_all ? 1 : 0;
     edge_caps(p->N, p->topk, e.connect, p->max_tools, &e.cap0, &e.cap);
     carve_edges(c, e);
@@ -1084,6 +1109,10 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         f.pred_pos = q.pp; f.pred_motion = q.pm;
         f.B = q.B; f.N = N; f.n_p = n_p; f.n_inst = p->n_instance; f.phys_dim = Pd;
         f.pstep = m->cfg.pstep; f.clamp = m->cfg.motion_clamp;
+        if (m->self_edges) {      // self-edge elision: the builder leaves class-0 / class-1 self-loops out of the lists, the encoder adds one row per class
+            e.self_attrs = f.attrs; e.self_class_row0 = f.self_class_row0;
+            f.self_info = e.self_info; f.self_rows = AG_SELF_ROWS;
+        }
         AgStepArgs &st = run[k].st;
         st.state = q.state; st.delta = delta + b0 * plane; st.pred_pos = q.pp;
         st.obj_mask = obj_mask ? obj_mask + b0 * n_p : nullptr; st.repeat = repeat + b0;

@@ -109,7 +109,23 @@ struct AgFwdArgs {
     const float *h_rows;             // node_update, round 0: residual h from compact rows (NULL: packed table h)
     // set per model step by ag_rollout: the edge builder's launches of this step already produced edge_node_tab / send_c (AgEdgeArgs riders)
     int tab_done, remap_done;
+    // ---- self-edge elision (r06; ag_rollout with the engine's own edge builder; option "self_edges").  A particle's self-loop (graph.py:68-75: d = 0 is
+    // always in radius and, barring >= top-k exact duplicates, in the top-k) has the edge inputs [a_n, a_n, |g_n - g_n| = 0, x_n - x_n = 0 ...]
+    // (model.py:228-253 with r = s): its relation_encode / Eterm row depends on the node's ATTRIBUTE CLASS only.  The builder leaves the self-loops of
+    // the two classes every driver of the reference produces — (1, 0) object, (0, 1) tool — out of the COO list the edge encoder walks and out of the
+    // per-edge table; the encoder computes ONE row per class instead (AG_SELF_ROWS synthetic edges appended behind the list: table rows E, E + 1), and
+    // the segment reduce adds that row at the self-loop's position in the receiver's (ascending-sender) order, so every sum keeps its order: same bits.
+    // self_info[g] = (class << 16) | position of the elided self-loop in g's row, or -1 (no self-loop, or another attribute pair: kept as a real edge);
+    // row_ptr / edge_recv / edge_send then describe the graph WITHOUT the elided edges.  NULL: nothing is elided (ag_forward on a caller's CSR).
+    const int32_t *self_info;
+    int self_class_row0;      // row of class 0 in edge_node_tab (= the layout's rows_pad) = the node id the synthetic edges carry as receiver and sender
+    int self_rows;            // synthetic class edges behind the COO list (AG_SELF_ROWS with elision, else 0): the edge encoders walk row_ptr[B N] + self_rows edges
 };
+#define AG_SELF_ROWS 2
+// rows of the per-edge table / entries of the COO arrays for a graph of at most e_cap edges (+ the class rows), in whole 256-row tiles
+__host__ __device__ __forceinline__ size_t ag_edge_rows_pad(long long e_cap) { return ((size_t)(e_cap > 0 ? e_cap : 1) + AG_SELF_ROWS + 255) / 256 * 256; }
+// attribute class of a node for self-edge elision: 0 = (1, 0), 1 = (0, 1), -1 = anything else
+__device__ __forceinline__ int ag_self_class(float a0, float a1) { return (a0 == 1.0f && a1 == 0.0f) ? 0 : ((a0 == 0.0f && a1 == 1.0f) ? 1 : -1); }
 #define AG_TILE_CTRS 4
 #define AG_DEDUP_REPS 8            // distinct node-encoder input rows shared within a sample (more than that: private rows)
 
@@ -170,34 +186,55 @@ __device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { const ag_f32x4 v =
 __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin_nontemporal_store(ag_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ag_f32x4 *>(p)); }
 #endif
 
+// An elided self-loop (AgFwdArgs::self_info) is a VIRTUAL edge: node g has n = (e1 - e0) + 1 of them, virtual edge j is table row / COO entry
+// e0 + j - (j > kself), except j == kself: the class row (table row E + class) and the node itself as the sender.
+struct AgSelfView {
+    int e0, n, kself, eself;
+    __device__ __forceinline__ int row(int j) const { return j == kself ? eself : e0 + j - (j > kself ? 1 : 0); }
+};
+__device__ __forceinline__ AgSelfView ag_self_view(const AgFwdArgs &a, int g)
+{
+    AgSelfView v;
+    const int e1 = a.row_ptr[g + 1];
+    v.e0 = a.row_ptr[g];
+    const int si = a.self_info ? a.self_info[g] : -1;
+    v.kself = si >= 0 ? (si & 0xffff) : 0x7fffffff;
+    v.eself = si >= 0 ? a.row_ptr[a.B * a.N] + (si >> 16) : 0;
+    v.n = e1 - v.e0 + (si >= 0 ? 1 : 0);
+    return v;
+}
+
 template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
 __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
 {
     const int f0 = ag_half_lane_feature(c);
-    const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
+    const AgSelfView sv = ag_self_view(a, g);
+    const int n = sv.n;
     const int4 *et = reinterpret_cast<const int4 *>(a.eterm) + c;          // segment c of row e: et[e * 20]
     const float *hs = a.hs + f0;
     const int4 *hq = reinterpret_cast<const int4 *>(a.hs) + c;             // HSQ: segment c of sender row s: hq[s * 20]
     const int exp_src = (group_lane0 + (c < 16 ? 17 : 19)) << 2;           // ds_bpermute byte address of the lane that loaded the exponent bytes
     const int exp_shift = c < 16 ? 8 * (c >> 2) : 0;
+    const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;      // (round 0 with node de-duplication: the node's compact row)
+    // sender of virtual edge j: the COO entry, or the node itself (in the numbering edge_send uses: its own Hr row index) for the elided self-loop
+    auto sender = [&](int j) { return j < n ? (j == sv.kself ? (int)gr : a.edge_send[sv.row(j)]) : -1; };
     int s[kInFlight];
 #pragma unroll
-    for (int i = 0; i < kInFlight; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
-    const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;      // (round 0 with node de-duplication: the node's compact row)
+    for (int i = 0; i < kInFlight; ++i) s[i] = sender(i);
     const float4 hr0 = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + f0);
     const float4 hr1 = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + f0 + 8);
     acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
     acc1 = acc0;
-    for (int e = e0; e < e1; e += kInFlight) {       // e0, e1 and with them every branch below are uniform over the node's 20 lanes
+    for (int e = 0; e < n; e += kInFlight) {       // n and with it every branch below are uniform over the node's 20 lanes
         int sn[kInFlight];
 #pragma unroll
-        for (int i = 0; i < kInFlight; ++i) sn[i] = e + kInFlight + i < e1 ? a.edge_send[e + kInFlight + i] : -1;
+        for (int i = 0; i < kInFlight; ++i) sn[i] = sender(e + kInFlight + i);
         int4 t[kInFlight], v[HSQ ? kInFlight : 1];
         float4 u0[HSQ ? 1 : kInFlight], u1[HSQ ? 1 : kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                t[i] = ag_ld_nt(&et[(size_t)(e + i) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
+                t[i] = ag_ld_nt(&et[(size_t)sv.row(e + i) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
                 if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
                 else {
                     u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
@@ -276,6 +313,13 @@ struct AgEdgeArgs {
     const int32_t *map_node_row;                      // (B*N) compact row of every node
     const int *map_ovf;                               // device flag: this call runs without de-duplication (identity map)
     int32_t *map_send_c;                              // (E); NULL: no rider
+    // Self-edge elision (ag_rollout only; AgFwdArgs::self_info): with `self_attrs` set, the self-loops of nodes of attribute class 0 / 1 are left out of
+    // row_ptr / edge_recv / edge_send, their position in the row goes to self_info, and AG_SELF_ROWS synthetic entries (recv = send = self_class_row0 + k:
+    // the class rows of the per-node input table) are appended behind the list.
+    const float *self_attrs;                          // (B, N, 2); NULL: off
+    int32_t *self_info;                               // (B*N) out
+    int32_t *self_pos;                                // (B*N) workspace: position of the elidable self-loop in the row, or -1 (scan_partial -> rowptr_scatter)
+    int self_class_row0;                              // node-table row of class 0 (= rows_pad of the forward layout)
 };
 enum { AG_RIDER_TAB = 1, AG_RIDER_MAP = 2 };
 int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns the riders its launches carried (AG_RIDER_*)
@@ -284,9 +328,16 @@ int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns t
 // two indexed 64-byte rows per edge: [attr0, attr1, group0, 0 | v0 | v1 | v2 | x_cur], v_i = state[i+1] - state[i].  The per-edge features are
 // then plain differences of two rows — the same subtractions in the same order as (pr[i+1] - pr[i]) - (ps[i+1] - ps[i]) in edge_features.
 // One thread per node g; shared by edge_node_tab_kernel (ag_mlp.hip) and the rider workgroups of bin_kernel (ag_edges.hip).
+// `class_row0` >= 0 (self-edge elision): rows class_row0 + k, k < AG_SELF_ROWS, are the two endpoints of class k's synthetic self-edge — the class's
+// attribute pair, everything else zero, so that the edge features come out as a real self-loop's: [a, a, |0 - 0|, 0 - 0 ...] (written by thread k).
 __device__ __forceinline__ void ag_edge_node_tab_row(const float *state, const float *attrs, const float *p_instance, int n_inst, int n_p,
-                                                     int B, int N, float *tab, int *status, int g)
+                                                     int B, int N, float *tab, int *status, int g, long long class_row0 = -1)
 {
+    if (class_row0 >= 0 && g < AG_SELF_ROWS) {
+        float4 *dst = reinterpret_cast<float4 *>(tab + (size_t)(class_row0 + g) * 16);
+        dst[0] = make_float4(g == 0 ? 1.0f : 0.0f, g == 0 ? 0.0f : 1.0f, 0.0f, 0.0f);
+        dst[1] = dst[2] = dst[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (g >= B * N) return;
     const int b = g / N, i = g - b * N;
     float p[AG_NHIS][3];

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     __shared__ GridParams G;
     if ((int)blockIdx.x >= a.B) {       // rider workgroups (ag_rollout): the model step's per-node input rows of the edge features, a function of the state only
         ag_edge_node_tab_row(a.tab_state, a.tab_attrs, a.tab_pinst, a.tab_n_inst, a.tab_n_p, a.B, a.N, a.tab_out, a.tab_status,
-                             ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x);
+                             ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x, a.self_attrs ? (long long)a.self_class_row0 : -1);
         return;
     }
     const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -729,12 +729,55 @@ __global__ __launch_bounds__(256) void finalize_connect_sweep_kernel(AgEdgeArgs 
 // ---- exclusive scan of the per-row degrees -> row_ptr, then COO fill -----------------------------
 constexpr int kScanRows = 256;    // rows per block (one per thread; ag_api.hip sizes blk_sum with the same number)
 
-__global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a)
+// Self-edge elision (AgEdgeArgs::self_attrs): a row's self-loop is left out of the lists when the node's attribute pair is class 0 / 1
+// (ag_self_class).  Its position in the (ascending) sender row is found here — the workgroup's 256 rows staged through LDS with coalesced
+// loads, each thread then walks its own row — and handed to rowptr_scatter_kernel in self_pos; the scanned degree excludes it.
+__device__ __forceinline__ int self_position(const AgEdgeArgs &a, const int32_t *sel, int cap, int *stage, int row0, int nloc, int deg)
 {
+    const int n = nloc * cap;
+    const int32_t *src = sel + (size_t)row0 * cap;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + 256 * u < n ? src[i0 + 256 * u] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n) stage[i0 + 256 * u] = v[u];
+    }
+    __syncthreads();
+    int pos = -1;
+    if ((int)threadIdx.x < nloc) {
+        const int r = row0 + threadIdx.x, me = r % a.N;
+        const int cls = ag_self_class(a.self_attrs[(size_t)r * 2], a.self_attrs[(size_t)r * 2 + 1]);
+        if (cls >= 0)
+            for (int k = 0; k < deg; ++k)
+                if (stage[threadIdx.x * cap + k] == me) pos = k;
+        if (pos > 0xffff) pos = -1;      // (self_info keeps the position in 16 bits; a longer row keeps its self-loop as a real edge)
+    }
+    return pos;
+}
+constexpr int kSelfStageMax = 256 * 40;      // ints of LDS for the staged rows; rows longer than 40 slots (top-k + tools) are read from global memory
+
+__global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
+{
+    __shared__ int stage[kSelfStageMax];
     const int rows = a.B * a.N;
     const int r = blockIdx.x * kScanRows + threadIdx.x;
+    int d = r < rows ? a.deg[r] : 0;
+    if (a.self_attrs) {
+        const int row0 = blockIdx.x * kScanRows, nloc = rows - row0 < kScanRows ? rows - row0 : kScanRows;
+        int pos = -1;
+        if (cap * 256 <= kSelfStageMax) pos = self_position(a, sel, cap, stage, row0, nloc, d);
+        else if (r < rows && ag_self_class(a.self_attrs[(size_t)r * 2], a.self_attrs[(size_t)r * 2 + 1]) >= 0) {
+            const int me = r % a.N;
+            for (int k = 0; k < d && k <= 0xffff; ++k)
+                if (sel[(size_t)r * cap + k] == me) pos = k;
+        }
+        if (r < rows) a.self_pos[r] = pos;
+        d -= pos >= 0 ? 1 : 0;
+    }
     int total;
-    block_exclusive_scan(r < rows ? a.deg[r] : 0, &total);
+    block_exclusive_scan(d, &total);
     if (threadIdx.x == 0) a.blk_sum[blockIdx.x] = total;
 }
 
@@ -744,7 +787,7 @@ __global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a)
 // (r05: was scan_blocks + rowptr + scatter, three launches of 5 + 5 + 11 us at C2.)
 __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
 {
-    __shared__ int s_ptr[kScanRows], s_deg[kScanRows];
+    __shared__ int s_ptr[kScanRows], s_deg[kScanRows], s_self[kScanRows];
     const int rows = a.B * a.N;
     // rider (ag_rollout, de-duplicated node encoder): the sender column mapped to compact rows for round 0's reduce, written where edge_send is.
     // (The overflow word is read here, with the partial sums, not in front of the loop that uses it: one memory round trip less on the chain.)
@@ -756,12 +799,21 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
     block_exclusive_scan(part, &base);
     const int r = blockIdx.x * kScanRows + threadIdx.x;
     const int d = r < rows ? a.deg[r] : 0;
+    // self-edge elision: the row's self-loop (slot ks) is not stored; self_info tells the segment reduce where it belongs
+    const int ks = (a.self_attrs && r < rows) ? a.self_pos[r] : -1;
+    if (a.self_attrs && r < rows)
+        a.self_info[r] = ks >= 0 ? ((ag_self_class(a.self_attrs[(size_t)r * 2], a.self_attrs[(size_t)r * 2 + 1]) << 16) | ks) : -1;
     int total;
-    const int off = base + block_exclusive_scan(d, &total);
+    const int off = base + block_exclusive_scan(d - (ks >= 0 ? 1 : 0), &total);
     s_ptr[threadIdx.x] = off;
     s_deg[threadIdx.x] = d;
+    s_self[threadIdx.x] = ks >= 0 ? ks : 0x7fffffff;
     if (r < rows) a.row_ptr[r] = off;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.row_ptr[rows] = base + total;
+    if (a.self_attrs && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < AG_SELF_ROWS) {      // the class rows' synthetic edges, behind the list
+        a.edge_recv[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x;
+        a.edge_send[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x;
+    }
     __syncthreads();
     const int row0 = blockIdx.x * kScanRows;
     const int nloc = rows - row0 < kScanRows ? rows - row0 : kScanRows;
@@ -777,9 +829,9 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
             e[u] = -1; sg[u] = 0;
             if (idx >= n) continue;
             const int lr = idx / cap, slot = idx - lr * cap;
-            if (slot >= s_deg[lr]) continue;
+            if (slot >= s_deg[lr] || slot == s_self[lr]) continue;
             const int row = row0 + lr;
-            e[u] = s_ptr[lr] + slot;
+            e[u] = s_ptr[lr] + slot - (slot > s_self[lr] ? 1 : 0);
             sg[u] = (row / a.N) * a.N + v[u];
             a.edge_recv[e[u]] = row;
             a.edge_send[e[u]] = sg[u];
@@ -840,7 +892,7 @@ int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
         cap = a.cap;
     }
     const int nblk = (rows + kScanRows - 1) / kScanRows;
-    hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(scan_partial_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
     hipLaunchKernelGGL(rowptr_scatter_kernel, dim3(nblk), dim3(256), 0, s, a, sel, cap);
     if (a.map_send_c) riders |= AG_RIDER_MAP;
     return riders;

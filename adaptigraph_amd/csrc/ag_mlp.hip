@@ -979,7 +979,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn];
+    const int E = a.row_ptr[Mn] + a.self_rows;      // (+ the class rows of elided self-loops, AgFwdArgs::self_info: synthetic edges behind the list)
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
@@ -992,7 +992,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         q.claim();
         const int e = tile * AG_ROWS_PER_BLOCK + wave * 32 + j;
         const bool valid = e < E;
-        const int r = valid ? a.edge_recv[e] : 0, s = valid ? a.edge_send[e] : 0;
+        int r = valid ? a.edge_recv[e] : 0, s = valid ? a.edge_send[e] : 0;
+        // synthetic self-edge of attribute class r - class_row0 (self-edge elision): [a, a, 0, 0 ...] — a real self-loop's inputs (x - x = +0)
+        const int cls = (a.self_rows && r >= a.self_class_row0) ? r - a.self_class_row0 : -1;
+        if (cls >= 0) r = s = 0;
         const int b = r / a.N, ri = r - b * a.N, si = s - b * a.N;
 
         float feat[24];
@@ -1000,6 +1003,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         for (int k = 0; k < 24; ++k) feat[k] = 0.0f;
         feat[0] = a.attrs[(size_t)r * 2]; feat[1] = a.attrs[(size_t)r * 2 + 1];
         feat[2] = a.attrs[(size_t)s * 2]; feat[3] = a.attrs[(size_t)s * 2 + 1];
+        if (cls >= 0) { feat[0] = feat[2] = cls == 0 ? 1.0f : 0.0f; feat[1] = feat[3] = cls == 0 ? 0.0f : 1.0f; }
         {
             float gd = 0.0f;   // g = cat([p_instance, 0]) (model.py:235), group_diff = sum |g_r - g_s| (:238)
             for (int ii = 0; ii < a.n_inst; ++ii) {
@@ -1026,6 +1030,9 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
                 for (int c = 0; c < 3; ++c) feat[5 + hh * 3 + c] = (pr[hh + 1][c] - pr[hh][c]) - (ps[hh + 1][c] - ps[hh][c]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) feat[5 + (AG_NHIS - 1) * 3 + c] = pr[AG_NHIS - 1][c] - ps[AG_NHIS - 1][c];
+            if (cls >= 0)      // (node 0 stood in for the class row's endpoints: its differences with itself are +0 unless it is non-finite)
+#pragma unroll
+                for (int k = 5; k < AG_EDGE_IN; ++k) feat[k] = 0.0f;
         }
         f32x16 in0;
 #pragma unroll
@@ -1300,7 +1307,8 @@ __device__ __forceinline__ void ws_round_barrier() { asm volatile("s_waitcnt lgk
 __global__ __launch_bounds__(256) void edge_node_tab_kernel(AgFwdArgs a, int nb_tab)
 {
     if ((int)blockIdx.x >= nb_tab) { send_remap_body(a, (int)blockIdx.x - nb_tab, (int)gridDim.x - nb_tab); return; }
-    ag_edge_node_tab_row(a.state, a.attrs, a.p_instance, a.n_inst, a.n_p, a.B, a.N, a.edge_node_tab, a.status, blockIdx.x * 256 + threadIdx.x);
+    ag_edge_node_tab_row(a.state, a.attrs, a.p_instance, a.n_inst, a.n_p, a.B, a.N, a.edge_node_tab, a.status, blockIdx.x * 256 + threadIdx.x,
+                         a.self_rows ? (long long)a.self_class_row0 : -1);
 }
 
 // First layer of one 32-edge block for out-tiles [T0, T0 + NT): per tile 2 k16-steps x (lo, hi) fp16 MFMAs with the A fragments read from the
@@ -1401,7 +1409,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn];
+    const int E = a.row_ptr[Mn] + a.self_rows;      // (+ the class rows of elided self-loops: their endpoints are the class rows of the per-node table)
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int nblk = (E + 31) / 32;
     if ((int)blockIdx.x >= nblk) return;
@@ -1411,7 +1419,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     for (int i = tid; i < AG_CHUNK_F4; i += 512) s_wf[i] = ws[i];
     for (int i = tid; i < (int)(sizeof(s_act) / 16); i += 512) reinterpret_cast<float4 *>(&s_act[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (int)(sizeof(s_in0) / 16); i += 512) reinterpret_cast<float4 *>(&s_in0[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t e_pad = ((size_t)(a.e_cap > 0 ? a.e_cap : 1) + 255) / 256 * 256;        // rows of the table (fwd_layout); dump rows start here
+    const size_t e_pad = ag_edge_rows_pad(a.e_cap);        // rows of the table (fwd_layout); dump rows start here
     auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
     auto slot_of = [](int i) { return (i + 4 * AG_WS_SLOTS) % AG_WS_SLOTS; };                 // i >= -12
     // this lane's 16 bytes of k16-step 0 of the fp16 image of input set `layer` (0: RE1, 1: RE2, 2: We), block i (i >= -8)
@@ -1742,7 +1750,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 // The streaming node_update_kernel re-reads its 15 weight chunks (300 KB) from L2 for every 128 rows: 0.60 GB per launch at C2 beside 0.74 GB
 // of tables, and the timing-only build without those copies is 17 % shorter (profiles/r05_node_update_ablation.txt).  Here ONE 256-thread
 // workgroup per CU (one wave per SIMD, 496 registers per lane) keeps all 15 (layer, out-tile) units' split-bf16 A operands in registers for
-// the whole launch — wave w owns out-tile w of each of the three layers, the fifth tiles go one each to waves 0, 1, 2 — and 32-row blocks
+// the whole launch — wave w owns out-tile w of each of the three layers, the fifth tiles go one each to waves 3 (first layer), 1 (Hr), 2 (Hs) — and 32-row blocks
 // flow through as a two-stage pipeline with ONE barrier per block:
 //     phase p:   first layer (h' = relu(W_pp[:, F:] agg + Pn + h)) of block p        input set X[p & 1]  -> h' to HBM + output set Y[p & 1]
 //                Hr / Hs layers of block p - 1 (one pass over the set for both)        input set Y[(p - 1) & 1]
@@ -1755,7 +1763,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
 struct NwsUnit { bf16x8 hi[10], lo[10]; };
 
 // ACC: the unit lives in the accumulation-register half of the file (the matrix instructions read their A operand from there directly): a
-// wave's first three units; the fourth (waves 0-2) sits in architectural registers.  Left to the compiler (builtin MFMAs), the 320 weight
+// wave's first three units; the fourth (waves 1-3) sits in architectural registers.  Left to the compiler (builtin MFMAs), the 320 weight
 // registers end up wherever it likes, with ~1 750 accumulation-register moves per block and spills.
 template <bool ACC>
 __device__ __forceinline__ void nws_load_unit(NwsUnit &W, const float4 *chunk, int lane)
@@ -1829,7 +1837,7 @@ __device__ __forceinline__ void nws_write_half(unsigned char *set_lane, int step
 template <int WAVE, bool HSQ>
 __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a, unsigned char *sX, unsigned char *sY)
 {
-    constexpr int N1 = WAVE == 3 ? 2 : 1, N2 = WAVE == 1 ? 2 : 1, N3 = WAVE == 2 ? 2 : 1;      // the fifth out-tiles: one each to waves 3, 1, 2
+    constexpr int N1 = WAVE == 3 ? 2 : 1, N2 = WAVE == 1 ? 2 : 1, N3 = WAVE == 2 ? 2 : 1;      // the fifth out-tiles: layer 1's to wave 3, Hr's to wave 1, Hs's to wave 2
     constexpr int N23 = N2 + N3;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int Mn = a.B * a.N;
@@ -1839,7 +1847,7 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
     const float *pn_rows = ovf ? nullptr : a.pn_rows, *h_rows = ovf ? nullptr : a.h_rows;
     NwsUnit U1[N1], U2[N2], U3[N3];
     const float4 *ws = w.node_mid_b3;
-    // placement: a wave's units U1[0], U2[0], U3[0] sit in accumulation registers (240), its fifth-tile unit (waves 0-2) in architectural ones
+    // placement: a wave's units U1[0], U2[0], U3[0] sit in accumulation registers (240), its fifth-tile unit (waves 1-3) in architectural ones
     nws_load_unit<true>(U1[0], ws + (size_t)(0 + WAVE) * AG_CHUNK_F4, lane);
     nws_load_unit<true>(U2[0], ws + (size_t)(5 + WAVE) * AG_CHUNK_F4, lane);
     nws_load_unit<true>(U3[0], ws + (size_t)(10 + WAVE) * AG_CHUNK_F4, lane);
@@ -1852,7 +1860,8 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
     constexpr int NS = WAVE < 2 ? 3 : 2;
     float4 raw[NS][2];
     auto stage_load = [&](int i) {
-        const size_t g = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
+        const size_t g0 = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
+        const size_t g = g0 < (size_t)Mn ? g0 : 0;       // rows past B*N (last block): the reduce never wrote them — node 0's row instead of stale workspace bytes
         const float *row = a.agg + g * AG_FP + 4 * h;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -2212,20 +2221,21 @@ void ag_launch_edge_encode(const AgWeights &w, const AgFwdArgs &a, hipStream_t s
 {
     if (a.e_cap <= 0) return;
     const dim3 block(AG_MLP_THREADS);
+    const int e_max = a.e_cap + a.self_rows;      // upper bound of the rows this launch encodes (the true count is on the device)
     if (a.precision == AG_PREC_B3 && a.eterm_half && a.edge_products == 2) {     // mode 2: two fp16 products per k16-step, three workgroups per CU
         if (a.edge_ws && a.n_inst <= 1 && (long long)a.B * a.N * 4 < 0x7fffffffLL) {        // weight-stationary: one workgroup per CU, 32-edge blocks
-            const int blocks = (a.e_cap + 31) / 32, slots = a.ws_blocks;
+            const int blocks = (e_max + 31) / 32, slots = a.ws_blocks;
             const int nb_tab = a.tab_done ? 0 : (a.B * a.N + 255) / 256;
             const int nb_map = a.dedup && !a.remap_done ? ((a.e_cap + 1023) / 1024 < 4096 ? (a.e_cap + 1023) / 1024 : 4096) : 0;      // four edges per thread
             if (nb_tab + nb_map > 0) hipLaunchKernelGGL(edge_node_tab_kernel, dim3(nb_tab + nb_map), dim3(256), 0, s, a, nb_tab);
             hipLaunchKernelGGL(edge_encode_ws_kernel, dim3(blocks < slots ? blocks : (slots > 0 ? slots : 1)), dim3(512), 0, s, w, a);   // (always eight waves, whatever AG_MLP_THREADS is)
             return;
         }
-        const dim3 grid(grid_for(a.e_cap, a.max_blocks / AG_MLP_WG_PER_CU * AG_H3_WG_PER_CU));
+        const dim3 grid(grid_for(e_max, a.max_blocks / AG_MLP_WG_PER_CU * AG_H3_WG_PER_CU));
         hipLaunchKernelGGL(edge_encode_kernel<PrecH3>, grid, block, 0, s, w, a);
         return;
     }
-    const dim3 grid(grid_for(a.e_cap, a.max_blocks));
+    const dim3 grid(grid_for(e_max, a.max_blocks));
     if (a.precision == AG_PREC_B3) hipLaunchKernelGGL(edge_encode_kernel<PrecB3>, grid, block, 0, s, w, a);
     else hipLaunchKernelGGL(edge_encode_kernel<PrecF32>, grid, block, 0, s, w, a);
 }

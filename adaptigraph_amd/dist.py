@@ -10,19 +10,28 @@ same action tensor and the gathered states are scored against the full one.  `re
 (broadcast from rank 0; `MPPIPlanner.sample` uses it for the sampled action sequences) and `assert_replicated()`
 checks it.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
-_BUFFERS = {}
+_BUFFERS = collections.OrderedDict()
+_BUFFERS_MAX = 8      # live shapes: (recv state_seqs, recv action_seqs, send pad) x the two batch sizes an MPPI loop alternates between
 
 
 def _buffer(tag, shape, dtype, device):
-    """Grow-never, shape-keyed scratch tensors for the collective (send pad / receive buffer): allocated once per shape."""
+    """Shape-keyed scratch tensors for the collective (send pad / receive buffer), allocated once per shape and kept in a small LRU: a planner
+    that varies its sample count from call to call must not pile up one receive buffer per count (the bug class forward_dynamics._constants
+    had).  A `copy=False` result is a view of such a buffer: valid until _BUFFERS_MAX other shapes have been gathered since."""
     key = (tag, tuple(shape), dtype, device.type, device.index)
     buf = _BUFFERS.get(key)
     if buf is None:
+        while len(_BUFFERS) >= _BUFFERS_MAX:
+            _BUFFERS.popitem(last=False)
         buf = torch.empty(shape, dtype=dtype, device=device)
         _BUFFERS[key] = buf
+    else:
+        _BUFFERS.move_to_end(key)
     return buf
 
 

@@ -29,6 +29,7 @@ Prints one JSON line on rank 0 (contract in the task statement) with
   ranks         (N > 1) per-rank rollout / all-gather milliseconds per step (min / max over ranks)
 """
 import argparse
+import contextlib
 import ctypes
 import hashlib
 import json
@@ -36,6 +37,7 @@ import os
 import sys
 import time
 
+_T_START = time.perf_counter()       # wall-clock legs of this process (`legs_s` in the JSON line): everything below is attributed to a named leg
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes needs it)
 
 import numpy as np
@@ -49,6 +51,19 @@ from adaptigraph_amd import _lib, configs, synth                       # noqa: E
 from adaptigraph_amd import dist as agdist                             # noqa: E402
 from adaptigraph_amd.forward_dynamics import dynamics                  # noqa: E402
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
+
+LEGS = {"import": time.perf_counter() - _T_START}      # (a fresh box pages torch + ROCm in from the image: minutes, not this program's doing)
+
+
+@contextlib.contextmanager
+def leg(name):
+    """Attribute the wall-clock of a block to `legs_s[name]` (accumulating; nested legs are the caller's business: none are nested here)."""
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        LEGS[name] = LEGS.get(name, 0.0) + time.perf_counter() - t0
+
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
@@ -101,31 +116,38 @@ def pmc_traffic(material, batch, precision, kernel):
     return (v, rec.get("source", "profiles/pmc_traffic.json")) if v is not None else (None, "workload not in profiles/pmc_traffic.json")
 
 
-def cpu_baseline(weights, material, n_obj, kw, seconds_budget=20.0):
-    """Oracle ("port" of the reference algorithm: dense-formulation forward, O(N^2) edge build, per-step rebuild)
-    on a bounded sample: ONE graph per host thread (the oracle's OpenMP loop runs over graphs, so a smaller batch would leave
-    threads idle: r02 timed 32 graphs on a 256-thread host), 2 rollout steps.  `cores` = threads that actually had a graph."""
+def cpu_baseline(weights, material, n_obj, kw, T=10, gpu_out=None):
+    """Oracle ("port" of the reference algorithm: dense-formulation forward, O(N^2) edge build, per-step rebuild) on the SAME inputs as the timed
+    GPU workload — the first `bsz` action samples of it, ONE graph per host thread (the oracle's OpenMP loop runs over graphs), all T rollout
+    steps, once: ~3.3 s per model step on the 256-thread GPU-box host.  Because it is the same workload, its result is also the reference
+    trajectory the engine's result is held against: `drift` = max |engine - oracle| over those samples after the T steps, per arithmetic mode
+    (`gpu_out`: mode -> engine state_seqs as numpy) — per STEP on identical graphs the deviation is <= 1e-5 (tests); over a rollout a top-k
+    near-tie can pick another neighbour and the trajectories part (profiles/r05_rollout_drift.txt), which is what this number shows.
+    A host with few threads runs fewer samples and, below 32 threads, fewer steps (then no drift is reported)."""
     from oracle import ag_oracle as ago
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # idle OpenMP threads sleep instead of spinning beside torch's own pool
     cores = os.cpu_count() or 1
-    bsz = max(1, min(cores, 512))
-    steps = 2
-    state, act = synth.make_mpc_inputs(material, n_obj, bsz, seed=0, len_lo=steps, len_hi=steps + 0.9, **kw)
+    B = 256
+    bsz = max(1, min(cores, B))
+    steps = T if cores >= 32 else 2
+    state, act = synth.make_mpc_inputs(material, n_obj, B, seed=0, len_lo=steps, len_hi=steps + 0.9, **kw)
+    act = act[:bsz]
     task = configs.task_config(material)
     ago.lib()
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        ago.dynamics(weights, task, state, act)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds_budget * 0.5:
-            break
-    return {"value": bsz * steps * reps / dt, "unit": "graph-steps/s", "cores": min(cores, bsz), "host_threads": cores, "kind": "port",
-            "sample": f"{material} n_obj={n_obj}, batch {bsz} (one graph per host thread), {steps}-step rollout x {reps} reps ({dt:.1f} s), "
-                      f"OpenMP over graphs: {min(cores, bsz)} of {cores} host threads busy"}
+    seq, _ = ago.dynamics(weights, task, state, act)
+    dt = time.perf_counter() - t0
+    res = {"value": bsz * steps / dt, "unit": "graph-steps/s", "cores": min(cores, bsz), "host_threads": cores, "kind": "port",
+           "sample": f"{material} n_obj={n_obj}: the first {bsz} of the timed workload's 256 action samples (one graph per host thread), the full "
+                     f"{steps}-step rollout, once ({dt:.1f} s), OpenMP over graphs: {min(cores, bsz)} of {cores} host threads busy"}
+    if gpu_out and steps == T:
+        res["drift"] = {k: float(np.abs(v[:bsz] - seq[:, 0]).max()) for k, v in gpu_out.items() if v is not None and v.shape[0] >= bsz}
+        res["drift_note"] = (f"max |engine - oracle| of the predicted positions after the {T}-step rollout over those {bsz} samples; one-step deviation on "
+                             "identical graphs is <= 1e-5 (gate 1e-4, tests/test_gpu_parity.py): larger values are top-k near-ties resolved differently")
+    return res
 
 
-def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=12.0):
+def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=8.0):
     """the reference's FORMULATION on the host cores — dense one-hot Rr/Rs and `bmm` gathers in PyTorch-CPU
     (oracle/torch_dense.py restates model.py:129-313), per step a radius-graph rebuild (the C oracle's O(N^2) builder, expanded
     to one-hots as graph.py:152-155 returns them) + forward + state shift.  Bounded sample: the batch the one-hots let fit."""
@@ -158,7 +180,7 @@ def cpu_baseline_dense(weights, material, n_obj, kw, seconds_budget=12.0):
     # graph-steps/s at 16 threads, 9.0 at 64, 0.3 at 256), so the thread count is swept and the best one is what is reported
     best, sweep = None, {}
     with torch.no_grad():
-        for th in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        for th in sorted({min(cores, c) for c in (8, 16, 32)}):
             torch.set_num_threads(th)
             rollout_once()                                   # warm-up (thread pool, allocator)
             t0 = time.perf_counter()
@@ -198,21 +220,36 @@ class Engine:
     def opt(self, name, value):
         _lib.check(self.L.ag_set_option(self.h, name.encode(), int(value)), f"ag_set_option({name})")
 
+    def get(self, name):
+        """The model's CURRENT value of an engine option (ag_get_option: what the library runs with, whatever set it — default, environment, ag_set_option)."""
+        v = ctypes.c_int()
+        _lib.check(self.L.ag_get_option(self.h, name.encode(), ctypes.byref(v)), f"ag_get_option({name})")
+        return int(v.value)
+
     def sync(self):
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None):
+    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None, tag="main", keep=False):
         """`batch` graphs per GPU (weak scaling) or, with `global_batch`, that many graphs split over the ranks (strong scaling:
-        BASELINE configs[3] = cloth batch 512 over 8 GPUs)."""
+        BASELINE configs[3] = cloth batch 512 over 8 GPUs).  `tag`: name of this run's wall-clock legs; `keep`: return the predicted states
+        (numpy) so that the CPU leg can hold them against the oracle's rollout of the same inputs."""
+        if tag == "main":          # the headline run is split into its own legs (set-up, warm-up, timed, roofline pass)
+            return self._run(batch, T, precision, streams, steps, warmup, profile, global_batch, tag, keep)
+        with leg(tag):
+            return self._run(batch, T, precision, streams, steps, warmup, profile, global_batch, tag, keep)
+
+    def _run(self, batch, T, precision, streams, steps, warmup, profile, global_batch, tag, keep):
         wl = WORKLOADS[self.material]
+        sub = (lambda n: leg(f"main_{n}")) if tag == "main" else (lambda n: contextlib.nullcontext())
         B_global = batch * self.world if global_batch is None else global_batch
         batch = -(-B_global // self.world)
-        state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
-        state = torch.from_numpy(state_np).to(self.dev)           # inputs resident in HBM before the timed region
-        action = torch.from_numpy(act_np).to(self.dev)
+        with sub("setup"):
+            state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
+            state = torch.from_numpy(state_np).to(self.dev)           # inputs resident in HBM before the timed region
+            action = torch.from_numpy(act_np).to(self.dev)
         timing = {} if self.world > 1 else None
 
         def one_pass(tm=None):
@@ -221,9 +258,10 @@ class Engine:
 
         self.opt("precision", PRECISIONS[precision])
         self.opt("rollout_streams", streams)
-        for _ in range(warmup):
-            out = one_pass()
-        self.sync()
+        with sub("warmup"):          # (the first pass also sizes the workspace and loads the code objects)
+            for _ in range(warmup):
+                out = one_pass()
+            self.sync()
         # the model's sticky numeric status (ag_model_status) is read-and-cleared by every dynamics() call: OR what those reads see, so the
         # line says whether ANY timed pass left the arithmetic's range (the final read below covers the last pass)
         status, take = [int(self.model.take_status())], self.model.take_status
@@ -239,18 +277,22 @@ class Engine:
             out = one_pass(timing)
         self.sync()
         dt = time.perf_counter() - t0
+        if tag == "main":
+            LEGS["main_timed"] = dt
         self.model.take_status = take
         status[0] |= int(self.model.take_status())
         assert out["state_seqs"].shape == (B_global, 1, wl["n_obj"], 3) and bool(torch.isfinite(out["state_seqs"]).all())
-        import ctypes
-        prm = _lib.RolloutParams(batch, wl["n_obj"] + synth.MATERIALS[self.material]["n_tools"], wl["n_obj"], 1, synth.MATERIALS[self.material]["topk"], 0, 0, T, 0, 0.0)
+        mm = synth.MATERIALS[self.material]
+        prm = _lib.RolloutParams(batch, wl["n_obj"] + mm["n_tools"], wl["n_obj"], 1, mm["topk"], 1 if mm["connect_tools_all"] else 0, mm["n_tools"], T, 0, 0.0)
         res = {"B_global": B_global, "dt": dt, "ms_per_step": dt / steps * 1e3, "value": B_global * T * steps / dt,
-               "streams": int(self.L.ag_rollout_streams_for(self.h, ctypes.byref(prm))),
-               "roofline": None, "roofline_hbm": None, "kernels": None, "model_status": status[0]}
+               "streams": int(self.L.ag_rollout_streams_for(self.h, ctypes.byref(prm))), "timed_s": dt,
+               "roofline": None, "roofline_hbm": None, "kernels": None, "model_status": status[0],
+               "out": out["state_seqs"][:, 0].cpu().numpy() if keep else None}
         if timing:
             res["rank_ms"] = (agdist.elapsed_ms(timing["rollout"]) / steps, agdist.elapsed_ms(timing["gather"]) / steps)
         if profile:
-            res.update(self.roofline_pass(one_pass, batch, precision, streams, min(3, max(1, steps))))
+            with sub("roofline"):
+                res.update(self.roofline_pass(one_pass, batch, precision, streams, min(3, max(1, steps))))
         return res
 
     def roofline_pass(self, one_pass, batch, precision, streams, n_prof):
@@ -301,7 +343,7 @@ class Engine:
                 # (default) round 0 reads Hr / Hs from a few compact rows, so the three rounds average (1 + 3 + 3) / 3 tables.  In the default
                 # mode the rounds after the first gather Hs from q16 rows (320 B per node): 2.5 tables there
                 later = 2.5 if precision == "fast" else 3.0
-                tables = (3.0 + 2 * later) / 3.0 if os.environ.get("AG_NODE_DEDUP", "1") == "0" else (1.0 + 2 * later) / 3.0
+                tables = (3.0 + 2 * later) / 3.0 if self.get("node_dedup") == 0 else (1.0 + 2 * later) / 3.0
                 nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * tables * 640
                 a_s = ms[ka] / cnt[ka] * 1e-3
                 t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
@@ -336,7 +378,7 @@ class DryEngine(Engine):
         if self.world > 1:
             dist.barrier()
 
-    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None):
+    def run(self, batch, T, precision, streams, steps, warmup, profile=True, global_batch=None, tag="main", keep=False):
         wl = WORKLOADS[self.material]
         B_global = batch * self.world if global_batch is None else global_batch
         state_np, act_np = synth.make_mpc_inputs(self.material, wl["n_obj"], B_global, seed=0, len_lo=T, len_hi=T + 0.9, **wl["kw"])
@@ -406,13 +448,17 @@ def main():
             else:
                 dist.init_process_group(backend)
 
+    LEGS["process_group"] = time.perf_counter() - _T_START - LEGS["import"]
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz")))
-    eng = DryEngine(args.material, dev, world) if args.dry_run else Engine(args.material, weights, dev, world)
-    if args.cu_split is not None:
-        eng.opt("cu_split", args.cu_split)
+    with leg("engine_build"):      # library load + weight packing + the first HIP context on this process
+        eng = DryEngine(args.material, dev, world) if args.dry_run else Engine(args.material, weights, dev, world)
+        if args.cu_split is not None:
+            eng.opt("cu_split", args.cu_split)
     T = args.rollout_steps
+    want_drift = world == 1 and not args.no_cpu_baseline and not args.dry_run and args.global_batch is None and args.batch == 256
     r = eng.run(args.batch, T, args.precision, args.streams, args.steps, args.warmup, profile=not args.no_profile,
-                global_batch=args.global_batch)
+                global_batch=args.global_batch, keep=want_drift)
+    gpu_out = {args.precision: r.get("out")}
     per_gpu = -(-r["B_global"] // world)
 
     tmax = torch.tensor([r["dt"]], dtype=torch.float64, device=dev)
@@ -427,32 +473,48 @@ def main():
                  "rollout_ms": {"min": float(tab[:, 1].min()), "max": float(tab[:, 1].max())},
                  "all_gather_ms": {"min": float(tab[:, 2].min()), "max": float(tab[:, 2].max())},
                  "note": "per step; rollout/all_gather from CUDA events around the local rollout and the collective"}
+        # first-contact record: did the collective library see N ranks, each on its own device?
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "local_rank": local, "device": None if args.dry_run else torch.cuda.current_device(),
+                                      "device_name": None if args.dry_run else torch.cuda.get_device_name(), "pid": os.getpid()})
+        nccl_v = None
+        try:
+            nccl_v = ".".join(map(str, torch.cuda.nccl.version())) if not args.dry_run else None
+        except Exception as e:      # noqa: BLE001
+            nccl_v = repr(e)
+        ranks["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "nccl_version": nccl_v,
+                         "devices": devs, "distinct_devices": len({d["device"] for d in devs}),
+                         "visible_gpus": 0 if args.dry_run else torch.cuda.device_count()}
     dt = float(tmax.item())
 
     extra = None
     if world == 1 and not args.no_extra and args.material == "rope":
         extra = {}
         if args.precision != "f32":
-            e = eng.run(args.batch, T, "f32", args.streams, max(2, args.steps // 2), 1, profile=not args.no_profile)
+            e = eng.run(args.batch, T, "f32", args.streams, max(2, args.steps // 2), 1, profile=not args.no_profile, tag="f32", keep=want_drift)
+            gpu_out["f32"] = e.get("out")
             extra["f32_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "model_status": e["model_status"],
                                  "arithmetic": DTYPE["f32"], "roofline": e["roofline"],
                                  "note": "same workload, ag_set_option(precision, 0): the mode that matches every reference rollout golden"}
         if args.precision == "fast":      # the middle mode: split-bf16 everywhere, fp32 per-edge table
-            e = eng.run(args.batch, T, "bf16x3", args.streams, max(2, args.steps // 2), 1, profile=False)
+            e = eng.run(args.batch, T, "bf16x3", args.streams, max(2, args.steps // 2), 1, profile=False, tag="bf16x3", keep=want_drift)
+            gpu_out["bf16x3"] = e.get("out")
             extra["bf16x3_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "arithmetic": DTYPE["bf16x3"],
                                     "model_status": e["model_status"],
                                     "note": "same workload, ag_set_option(precision, 1)"}
         if args.weights == "seed0":       # throughput does not depend on the weights; the numeric status must stay clean on trained ones too
-            et = Engine(args.material, dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained_rope.npz"))), dev, world)
-            x = et.run(args.batch, T, args.precision, args.streams, max(2, args.steps // 2), 1, profile=False)
+            with leg("trained"):
+                et = Engine(args.material, dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained_rope.npz"))), dev, world)
+            x = et.run(args.batch, T, args.precision, args.streams, max(2, args.steps // 2), 1, profile=False, tag="trained")
             extra["trained_weights"] = {"value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"], "precision": args.precision,
                                         "weights": "trained_rope (the reference's train() on a toy dataset, tools/gen_trained.py)",
                                         "model_status": x["model_status"]}
             del et
         extra["workloads"] = {}
         for mat, b, t, tag in (("granular", 128, 10, "BASELINE configs[2]"), ("cloth", 64, 20, "BASELINE configs[3], per-GPU share of batch 512 on 8 GPUs")):
-            e2 = Engine(mat, weights, dev, world)
-            x = e2.run(b, t, args.precision, args.streams, 3, 1, profile=not args.no_profile)
+            with leg(mat):
+                e2 = Engine(mat, weights, dev, world)
+            x = e2.run(b, t, args.precision, args.streams, 3, 1, profile=not args.no_profile, tag=mat)
             extra["workloads"][mat] = {"workload": f"{mat} {WORKLOADS[mat]['n_obj']} particles, batch {b}, {t}-step rollout ({tag})",
                                        "value": x["value"], "unit": "graph-steps/s", "ms_per_step": x["ms_per_step"], "model_status": x["model_status"],
                                        "precision": args.precision, "kernels": x["kernels"], "roofline": x["roofline"],
@@ -461,7 +523,8 @@ def main():
 
         try:        # BASELINE configs[4] on one GPU: per-iteration wall-clock of the MPPI loop (bench_mpc.py measures it at N GPUs)
             import bench_mpc
-            ms_it, _ = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision)
+            with leg("mpc"):
+                ms_it, _ = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision)
             extra["mpc"] = {"workload": "MPPI iteration: 1024 sampled pushes x 15-step rollout on rope-1000, chamfer + penalty cost, softmax update "
                                         "(BASELINE configs[4], 1 GPU)", "value": ms_it, "unit": "ms per iteration", "higher_is_better": False,
                             "graph_steps_per_s": 1024 * 15 / ms_it * 1e3, "precision": args.precision}
@@ -505,12 +568,19 @@ def main():
         if extra:
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"])
+            with leg("cpu_port"):
+                line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"], T, gpu_out if want_drift else None)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            for mode, d in line["cpu_baseline"].get("drift", {}).items():      # flat keys the driver's record keeps (VERDICT r05 weak #1a)
+                line["config"][f"{'fast' if mode == 'fast' else mode}_drift"] = float(f"{d:.3g}")
             try:        # second baseline object: the reference's dense formulation (slower than the sparse port above, so the headline ratio stays conservative)
-                line["cpu_baseline_dense_bmm"] = cpu_baseline_dense(weights, args.material, wl["n_obj"], wl["kw"])
+                with leg("cpu_dense"):
+                    line["cpu_baseline_dense_bmm"] = cpu_baseline_dense(weights, args.material, wl["n_obj"], wl["kw"])
             except Exception as e:      # noqa: BLE001 — a baseline leg must never lose the measured line
                 line["cpu_baseline_dense_bmm"] = {"error": repr(e)}
+        LEGS["total"] = time.perf_counter() - _T_START
+        line["legs_s"] = {k: round(v, 2) for k, v in LEGS.items()}
+        line["config"]["bench_wall_s"] = round(LEGS["total"], 1)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -75,6 +75,12 @@ int ag_model_destroy(ag_model *m);
  *                            (the node encoder sees no positions, model.py:168-195) and read through an index, once per ag_rollout call: 1 (default) =
  *                            where it pays (>= 32 768 node-rows x steps per call), 2 = always, 0 = never (once per node and model step).
  *                            Bit-identical results
+ *   "self_edges"       0/1   ag_rollout (the engine's own edge builder): 1 (default) = a particle's self-loop (graph.py:68-75; its edge inputs are
+ *                            [a_n, a_n, 0, 0 ...], model.py:228-253 with r = s, a function of the node's attribute pair only) is left out of the edge
+ *                            encoder and of the per-edge table for the attribute classes (1, 0) and (0, 1) — every driver of the reference produces
+ *                            nothing else — one table row per class is encoded instead and the segment reduce adds it at the self-loop's position
+ *                            in the receiver's order (10 % / 17 % / 5 % fewer rows at rope-1k / cloth-4k / granular-2k); other attribute pairs keep
+ *                            their self-loops as real edges.  0 = every edge through the pipeline.  Bit-identical results
  *   "cu_split"         0|8k  CU-partitioned rollout (off by default): the first `cu_split` CU-mask bits (cu_split / 8 CUs of every XCD) run the
  *                            MFMA-bound edge encoder, the other CUs the HBM-bound edge build / segment reduce / node update / state step, the batch
  *                            parts pipelined through the two partitions on two CU-masked queues (hipExtStreamCreateWithCUMask).  Bit-identical
@@ -85,6 +91,11 @@ int ag_model_destroy(ag_model *m);
  *                            per-edge Eterm table in 16-bit block-scaled fixed point (q16: half the dominant HBM stream); the same deviation
  *                            class as mode 1 at any motion size (random sweeps, trained weights, actions up to +-0.5) */
 int ag_set_option(ag_model *m, const char *name, int value);
+
+/* The model's CURRENT value of an option of ag_set_option — whatever set it (default, AG_* environment at ag_model_create, ag_set_option):
+ * what a caller that accounts for the engine's work (bench.py's roofline bytes) must ask instead of re-reading the environment.
+ * No reference counterpart (the reference has no engine options). */
+int ag_get_option(const ag_model *m, const char *name, int *value);
 
 /* Sticky numeric status of a model, read-and-clear (synchronises `stream`): bit 0 (AG_STATUS_NONFINITE) = some forward on this
  * model left the range of its arithmetic.  In precision mode 2 that is (a) an activation of the fp16 edge stack beyond +-65504 — detected in

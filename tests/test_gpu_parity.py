@@ -451,6 +451,101 @@ def test_dedup_overflow_falls_back_to_the_per_node_encoder(weights, mode, fuse):
         got = both()
         assert all(torch.isfinite(a).all() and torch.equal(a, b) for a, b in zip(got, ref))
     assert m.take_status() == 0
+
+
+@pytest.mark.parametrize("mode", ["fast", "bf16x3", "f32"])
+@pytest.mark.parametrize("material,n_obj,batch,steps", [("rope", 1000, 17, 3), ("granular", 2000, 3, 2), ("cloth", 1024, 4, 3), ("rope", 100, 5, 3)])
+def test_self_edge_elision_is_bitwise_the_full_pipeline(weights, mode, material, n_obj, batch, steps):
+    """ag_set_option("self_edges", 1) (default, r06): ag_rollout's edge builder leaves the self-loops of attribute classes (1, 0) / (0, 1) out of the
+    COO list and the per-edge table, the edge encoder computes one row per class (synthetic edges behind the list) and the segment reduce adds it at
+    the self-loop's position in the receiver's order — the same bits as every edge through the pipeline (option 0), in every arithmetic mode, with the
+    weight-stationary and the streaming edge encoder, the fused reduce, without node de-duplication, on two streams, with connect_tools_all (cloth:
+    the tool's own self-loop), with 5 tools (granular), on the brute-force edge path (N < 256) and through dynamics_masked's invalid slots."""
+    m = make_model(weights, material, prec=mode)
+    kw = dict(spacing=0.1) if material == "rope" else {}
+    state, act = synth.make_mpc_inputs(material, n_obj, batch, seed=11, len_lo=steps, len_hi=steps + 0.9, **kw)
+
+    def run():
+        return dynamics(t(state), t(act), m, DEV, _ppm(material))["state_seqs"].clone()
+
+    m.set_option("self_edges", 0)
+    ref = run()
+    m.set_option("self_edges", 1)
+    assert torch.isfinite(ref).all() and torch.equal(ref, run())
+    variants = [("node_dedup", 0, 1), ("rollout_streams", 2, 0)]
+    if mode == "fast":
+        variants += [("edge_stationary", 0, 1), ("fuse_aggregate", 2, 0)]
+    for name, val, back in variants:
+        m.set_option(name, val)
+        assert torch.equal(ref, run()), name
+        m.set_option(name, back)
+    if material == "rope" and n_obj == 1000:      # invalid object slots (no self-loop there), per-sample masks
+        rng = np.random.default_rng(2)
+        st = np.repeat(state[None], 4, 0) + rng.normal(0, 0.002, (4,) + state.shape).astype(np.float32)
+        sm = rng.uniform(size=(4, n_obj)) < 0.8
+        a4 = act[:4, 0]
+        got = dynamics_masked(t(st), t(sm), t(a4), m, DEV, _ppm(material))["state_seqs"].clone()
+        m.set_option("self_edges", 0)
+        assert torch.equal(got, dynamics_masked(t(st), t(sm), t(a4), m, DEV, _ppm(material))["state_seqs"])
+    assert m.take_status() == 0
+
+
+@pytest.mark.parametrize("mode", ["fast", "f32"])
+def test_self_edge_elision_keeps_other_attribute_pairs_and_duplicate_particles(weights, mode):
+    """Only the attribute pairs (1, 0) and (0, 1) have a class row: a node with any other pair keeps its self-loop as a real edge.  And a self-loop
+    that the top-k rule drops (more than top-k exact duplicates of a particle with lower indices) is not there to elide.  Same bits as option 0."""
+    m = make_model(weights, "rope", prec=mode)
+    g = synth.make_graph_inputs("rope", 600, 3, seed=31, spacing=0.1)
+    rng = np.random.default_rng(4)
+    odd = rng.uniform(size=g["attrs"].shape[:2]) < 0.3
+    g["attrs"][odd] = np.array([0.5, 0.25], np.float32)
+    g["attrs"][0, 5] = np.array([1.0, 1.0], np.float32)
+    g["state"][1, :, 100:130] = g["state"][1, :, 100:101]          # 30 exact duplicates: top-k (10) keeps the ten lowest indices for every one of them
+    thr = aggraph.threshold_sq(0.5, 3, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    rep = torch.full((3,), 3, dtype=torch.int32, device=DEV)
+
+    def run():
+        return rollout(m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]), thr, rep, 3,
+                       10, False, 1).clone()
+
+    m.set_option("node_dedup", 2)
+    m.set_option("self_edges", 0)
+    ref = run()
+    m.set_option("self_edges", 1)
+    assert torch.isfinite(ref).all() and torch.equal(ref, run())
+    assert m.take_status() == 0
+
+
+@pytest.mark.parametrize("mode", ["fast", "bf16x3"])
+@pytest.mark.parametrize("node_ws", [1, 0])
+def test_stale_workspace_bytes_never_reach_the_results_or_the_status(weights, mode, node_ws):
+    """the weight-stationary node_update read `agg` rows past B*N when B*N is not a multiple of 32 — rows the segment
+    reduce never writes, i.e. whatever the grow-only workspace held (a NaN there raised a spurious AG_STATUS through the q16 store of the padded
+    Hs rows).  Fill every scratch buffer with 0xFF bytes (NaN as fp32, -1 as int32) in front of a forward and a bsz = 1 rollout at N = 1001:
+    same bits as before the fill, status 0."""
+    m = make_model(weights, "rope", prec=mode)
+    m.set_option("node_stationary", node_ws)
+    m.set_option("node_dedup", 2)
+    g = synth.make_graph_inputs("rope", 1000, 1, seed=23, spacing=0.1)
+    assert g["attrs"].shape[1] % 32 != 0
+    csr = aggraph.build_edges(t(g["state"][:, -1]), 0.5, t(g["mask"]), t(g["tool_mask"]), 10, False, "batch", max_tools=1)
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    kwp = {"action": t(g["action"]), "rope_physics_param": t(g["phys"])}
+    state, act = synth.make_mpc_inputs("rope", 1000, 1, seed=3, len_lo=3, len_hi=3.9, spacing=0.1)
+
+    def both():
+        pos, mot = m(*args, **kwp)
+        return pos.clone(), mot.clone(), dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"].clone()
+
+    ref = both()
+    assert m.take_status() == 0
+    for _ in range(2):
+        torch.cuda.synchronize()
+        for buf in aggraph._WS.values():
+            buf.fill_(0xFF)
+        got = both()
+        assert all(torch.isfinite(a).all() and torch.equal(a, b) for a, b in zip(got, ref))
+        assert m.take_status() == 0
     # and the same model right afterwards on inputs that DO fit: the flag is per call
     g2 = synth.make_graph_inputs("rope", 300, 2, seed=1, spacing=0.1)
     csr2 = aggraph.build_edges(t(g2["state"][:, -1]), 0.5, t(g2["mask"]), t(g2["tool_mask"]), 10, False, "batch", max_tools=1)
