@@ -23,15 +23,23 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     // XCD-aware block -> node-range mapping: the dispatcher puts block b on XCD b % 8 (MI355X_MICROARCH.md
     // §Workgroup dispatch); give each XCD a contiguous range of nodes (= whole graphs) so the gathered
     // Hs rows of a graph stay in ONE XCD's L2 instead of being replicated in all eight.
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-
+    // (shared-state rollout: the row count is a device word and the grid a capped upper bound — the workgroups stride over the blocks that exist;
+    // otherwise gridDim.x IS the block count and the loop runs once)
+    const int rows = ag_rows(a);
+    const int nb = a.n_rows_dev ? (rows + kNodesPerBlock - 1) / kNodesPerBlock : (int)gridDim.x;
     const int tid = threadIdx.x;
+    __shared__ float4 s_self[AG_SELF_ROWS * (AG_FP / 4)];      // the class rows of elided self-loops: one fetch per workgroup (see ag_reduce_node_q16)
+    if (a.self_info) {      // (uniform)
+        if (tid < AG_SELF_ROWS * (AG_FP / 4)) s_self[tid] = reinterpret_cast<const float4 *>(a.eterm)[(size_t)ag_edges(a) * (AG_FP / 4) + tid];
+        __syncthreads();
+    }
     if (tid >= kNodesPerBlock * 40) return;
     const int slot = tid / 40, c = tid - slot * 40;
+    for (int bid = blockIdx.x; bid < nb; bid += gridDim.x) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int g = logical * kNodesPerBlock + slot;
-    if (g >= a.B * a.N) return;
+    if (g >= rows) continue;
     const AgSelfView sv = ag_self_view(a, g);      // (an elided self-loop is a virtual edge: ag_common.h)
     const int n = sv.n;
     constexpr int kFly = 4;   // edges in flight per lane, sender indices fetched one iteration ahead (see aggregate_half_kernel)
@@ -50,7 +58,8 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 #pragma unroll
         for (int i = 0; i < kFly; ++i)
             if (s[i] >= 0) {
-                t[i] = ag_ld_nt(reinterpret_cast<const float4 *>(a.eterm + (size_t)sv.row(e + i) * AG_FP + 4 * c));
+                if (e + i == sv.kself) t[i] = s_self[sv.cls * (AG_FP / 4) + c];
+                else t[i] = ag_ld_nt(reinterpret_cast<const float4 *>(a.eterm + (size_t)(sv.e0 + e + i - (e + i > sv.kself ? 1 : 0)) * AG_FP + 4 * c));
                 u[i] = *reinterpret_cast<const float4 *>(a.hs + (size_t)s[i] * AG_FP + 4 * c);
             }
 #pragma unroll
@@ -64,6 +73,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
     }
     ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + 4 * c), acc);
     if (a.status && !isfinite((acc.x + acc.y) + (acc.z + acc.w))) atomicOr(a.status, 1);
+    }
 }
 
 // Same reduction over the 16-bit table of precision mode 2 (q16, ag_common.h: half the dominant HBM stream).  A row is 20 x 16 B; twenty
@@ -74,20 +84,29 @@ template <bool HSQ>
 __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 {
     ag_overflow_view(a);
-    const int nb = gridDim.x, bid = blockIdx.x;
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    if (a.agg_reverse) logical = nb - 1 - logical;
+    const int rows = ag_rows(a);      // (shared-state rollout: a device word, the grid a capped upper bound; otherwise gridDim.x is the block count: one trip)
+    const int nb = a.n_rows_dev ? (rows + kNodesPerBlockH - 1) / kNodesPerBlockH : (int)gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / AG_AGG_GROUP, c = lane - grp * AG_AGG_GROUP;
+    // the class rows of elided self-loops (table rows E, E + 1): one fetch per workgroup, read by every node from LDS
+    __shared__ int4 s_self[AG_SELF_ROWS * (AG_FP / 8)];
+    if (a.self_info) {      // (uniform)
+        if (threadIdx.x < AG_SELF_ROWS * (AG_FP / 8)) s_self[threadIdx.x] = reinterpret_cast<const int4 *>(a.eterm)[(size_t)ag_edges(a) * (AG_FP / 8) + threadIdx.x];
+        __syncthreads();
+    }
     if (grp >= AG_AGG_NODES_PER_WAVE) return;
-    const int g = logical * kNodesPerBlockH + wave * AG_AGG_NODES_PER_WAVE + grp;
-    if (g >= a.B * a.N) return;
-    float4 acc0, acc1;
-    ag_reduce_node_q16<AG_AGG_IN_FLIGHT, HSQ>(a, g, c, grp * AG_AGG_GROUP, acc0, acc1);      // (6 or 8 edges in flight with the q16 sender table: no change)
-    const int f0 = ag_half_lane_feature(c);
-    ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0), acc0);
-    ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8), acc1);
+    for (int bid = blockIdx.x; bid < nb; bid += gridDim.x) {
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (a.agg_reverse) logical = nb - 1 - logical;
+        const int g = logical * kNodesPerBlockH + wave * AG_AGG_NODES_PER_WAVE + grp;
+        if (g >= rows) continue;
+        float4 acc0, acc1;
+        ag_reduce_node_q16<AG_AGG_IN_FLIGHT, HSQ>(a, g, c, grp * AG_AGG_GROUP, acc0, acc1, a.self_info ? s_self : nullptr);      // (6 or 8 edges in flight with the q16 sender table: no change)
+        const int f0 = ag_half_lane_feature(c);
+        ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0), acc0);
+        ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8), acc1);
+    }
 }
 
 }  // namespace
@@ -95,12 +114,14 @@ __global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
 void ag_launch_aggregate(const AgFwdArgs &a, hipStream_t s)
 {
     const int nodes = a.B * a.N;
+    const int cap = a.n_rows_dev ? 8192 : 0x7fffffff;      // device-side row count: a bounded grid that strides over the blocks that exist
     if (a.eterm_half) {
-        const dim3 grid((nodes + kNodesPerBlockH - 1) / kNodesPerBlockH);
+        const int nbh = (nodes + kNodesPerBlockH - 1) / kNodesPerBlockH;
+        const dim3 grid(nbh < cap ? nbh : cap);
         if (a.hs_q16) hipLaunchKernelGGL(aggregate_half_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(aggregate_half_kernel<false>, grid, dim3(256), 0, s, a);
         return;
     }
     const int nb = (nodes + kNodesPerBlock - 1) / kNodesPerBlock;
-    hipLaunchKernelGGL(aggregate_kernel, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(aggregate_kernel, dim3(nb < cap ? nb : cap), dim3(256), 0, s, a);
 }

@@ -245,6 +245,9 @@ struct ag_model {
     int self_edges = 1;         // ag_rollout: leave the self-loops of attribute classes (1, 0) / (0, 1) out of the per-edge pipeline — one table row per class, added by
                                 // the segment reduce at the self-loop's position (AgFwdArgs::self_info; env AG_SELF_EDGES / "self_edges" 0 = every edge through
                                 // the pipeline); bit-identical
+    int shared_state = 0;       // ag_rollout: roll the tool-less base trajectory out once and compute per sample only the rows that can differ from it
+                                // (ag_shared.hip; env AG_SHARED_STATE / "shared_state"); bit-identical; off by default (the headline benchmark is quoted on the
+                                // full per-sample work)
     int node_dedup = 1;         // encode each distinct node-encoder input row of a sample once (env AG_NODE_DEDUP / "node_dedup"): 0 = never (every node,
                                 // every step), 1 = where it pays (default: >= 32 768 node-rows x steps per call; below that the two extra small launches cost
                                 // more than the shorter kernels save: 0.126 vs 0.115 ms for one 100-particle forward), 2 = always
@@ -343,7 +346,7 @@ struct FwdLayout {
     size_t rows_pad, e_pad, rows_c;
 };
 
-FwdLayout fwd_layout(int B, int N, int64_t e_cap)
+FwdLayout fwd_layout(int B, int N, int64_t e_cap, bool full_dedup = false)
 {
     FwdLayout L;
     L.rows_pad = align_up((size_t)B * N, AG_ROWS_PER_BLOCK);
@@ -351,12 +354,15 @@ FwdLayout fwd_layout(int B, int N, int64_t e_cap)
     // compact rows of the de-duplicated node encoder: AG_DEDUP_REPS shared rows per sample + a bounded private budget (the reference's drivers
     // use 2 rows per sample; until r04 this was sized for "every node private": 4 x B (N + 8) rows, 10.7 GB at the planner's 20 000 x 200)
     L.rows_c = align_up((size_t)B * AG_DEDUP_REPS + std::max<size_t>((size_t)B * N / 16, 1024), AG_ROWS_PER_BLOCK);
+    // shared-state rollout: the propagation tables are numbered by compact row, so the per-node fallback of an overflowing call has nowhere to
+    // write — a private row for every node instead (the budget cannot overflow)
+    if (full_dedup) L.rows_c = align_up((size_t)B * (AG_DEDUP_REPS + (size_t)N), AG_ROWS_PER_BLOCK);
     return L;
 }
 
-void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap, bool eterm16 = false)
+void carve_forward(Carver &c, AgFwdArgs &a, int B, int N, int64_t e_cap, bool eterm16 = false, bool full_dedup = false)
 {
-    const FwdLayout L = fwd_layout(B, N, e_cap);
+    const FwdLayout L = fwd_layout(B, N, e_cap, full_dedup);
     const size_t rc = L.rows_c + AG_ROWS_PER_BLOCK;              // + dump rows of the encoder's out-of-range lanes
     a.h = c.take<float>(L.rows_pad * AG_FP);
     a.pn = c.take<float>(L.rows_pad * AG_FP);
@@ -554,6 +560,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
     if (const char *v = getenv("AG_SELF_EDGES")) m->self_edges = atoi(v) != 0;
+    if (const char *v = getenv("AG_SHARED_STATE")) m->shared_state = atoi(v) != 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -806,6 +813,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     else if (!strcmp(name, "node_stationary")) m->node_ws = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "self_edges")) m->self_edges = value != 0;
+    else if (!strcmp(name, "shared_state")) m->shared_state = value != 0;
     else if (!strcmp(name, "cu_split")) {
         if (value != 0 && (value < 8 || value > m->n_cus - 8 || (value & 7)))
             return fail(AG_ERR_ARG, "ag_set_option: cu_split takes 0 (off) or a multiple of 8 in [8, %d], not %d", m->n_cus - 8, value);
@@ -827,6 +835,7 @@ int ag_get_option(const ag_model *m, const char *name, int *value)
     else if (!strcmp(name, "node_stationary")) *value = m->node_ws;
     else if (!strcmp(name, "node_dedup")) *value = m->node_dedup;
     else if (!strcmp(name, "self_edges")) *value = m->self_edges;
+    else if (!strcmp(name, "shared_state")) *value = m->shared_state;
     else if (!strcmp(name, "cu_split")) *value = m->cu_split;
     else return fail(AG_ERR_ARG, "ag_get_option: unknown option '%s'", name);
     return AG_OK;
@@ -1017,8 +1026,133 @@ static int ensure_partition(ag_model *m)
     return AG_OK;
 }
 
+// ---- shared-state rollout (ag_shared.hip): one stream, the batch as ONE part behind the base sample -------------------------------------------------
+struct SharedLayout {
+    AgSharedArgs sh{};
+    AgFwdArgs f{};
+    AgEdgeArgs e{};
+    float *pred_pos = nullptr, *pred_motion = nullptr;
+};
+
+static bool shared_applicable(const ag_model *m, const ag_rollout_params *p)
+{
+    if (!m || !p || !m->shared_state || p->B < 2 || p->n_steps < 1) return false;
+    if (m->fuse_agg != 0 || m->cu_split != 0) return false;      // (the fused reduce and the CU-partitioned pipeline keep the plain path)
+    if ((long long)(p->B + 1) * (p->N + AG_DEDUP_REPS) >= 0x7fffff00LL) return false;
+    if (ag_edge_capacity(p->B + 1, p->N, p->topk, p->connect_tools_all, p->max_tools) >= 0x7fffff00LL) return false;
+    return true;
+}
+
+static void carve_shared(Carver &c, const ag_model *m, const ag_rollout_params *p, SharedLayout &L, bool eterm16)
+{
+    const int B1 = p->B + 1, N = p->N, n_p = p->n_p, H = AG_NHIS, Pd = m->cfg.phys_dim, I = p->n_instance;
+    const int64_t e_cap = ag_edge_capacity(B1, N, p->topk, p->connect_tools_all, p->max_tools);
+    const size_t rows = (size_t)B1 * N, ecoo = (size_t)e_cap + 1 + AG_SELF_ROWS;
+    AgSharedArgs &s = L.sh;
+    s.s_state = c.take<float>(rows * H * 3);
+    s.s_delta = c.take<float>(rows * 3);
+    s.s_attrs = c.take<float>(rows * 2);
+    s.s_pinst = c.take<float>((size_t)B1 * n_p * (I > 0 ? I : 1));
+    s.s_phys = c.take<float>((size_t)B1 * (Pd > 0 ? Pd : 1));
+    s.s_thr = c.take<float>(B1);
+    s.s_mask = c.take<uint8_t>(rows);
+    s.s_tool = c.take<uint8_t>(rows);
+    s.s_obj_mask = c.take<uint8_t>((size_t)B1 * n_p);
+    s.s_repeat = c.take<int32_t>(B1);
+    s.dirty = c.take<uint8_t>(rows);
+    s.sel_a = c.take<uint8_t>(rows);
+    s.sel_b = c.take<uint8_t>(rows);
+    s.cmap = c.take<int32_t>(rows);
+    s.orig = c.take<int32_t>(rows);
+    s.row_ptr_c = c.take<int32_t>(rows + 1);
+    s.self_info_c = c.take<int32_t>(rows);
+    s.node_row_c = c.take<int32_t>(rows + AG_ROWS_PER_BLOCK);
+    s.recv_o = c.take<int32_t>(ecoo);
+    s.send_o = c.take<int32_t>(ecoo);
+    s.send_r0 = c.take<int32_t>(ecoo);
+    s.send_cm = c.take<int32_t>(ecoo);
+    s.blk_cnt = c.take<int32_t>(rows / 256 + 2);
+    s.blk_deg = c.take<int32_t>(rows / 256 + 2);
+    s.n_rows = c.take<int>(4);
+    s.n_edges = s.n_rows + 1;
+    L.pred_pos = c.take<float>(rows * 3 + 4);
+    L.pred_motion = c.take<float>(rows * 3 + 4);
+    AgEdgeArgs &e = L.e;
+    e.row_ptr = c.take<int32_t>(rows + 1);
+    e.edge_recv = c.take<int32_t>(ecoo);
+    e.edge_send = c.take<int32_t>(ecoo);
+    e.self_info = c.take<int32_t>(rows);
+    e.self_pos = c.take<int32_t>(rows);
+    e.B = B1; e.N = N; e.connect = p->connect_tools_all ? 1 : 0;
+    edge_caps(N, p->topk, e.connect, p->max_tools, &e.cap0, &e.cap);
+    carve_edges(c, e);
+    carve_forward(c, L.f, B1, N, e_cap, eterm16, true);
+    L.f.e_cap = (int)e_cap;
+}
+
+static int rollout_shared(ag_model *m, const ag_rollout_params *p, const float *state0, const float *delta, const float *attrs,
+                          const float *p_instance, const float *phys, const uint8_t *mask, const uint8_t *tool_mask, const uint8_t *obj_mask,
+                          const float *thr_sq, const int32_t *repeat, float *out_seq, float *state_final, void *workspace, size_t workspace_bytes,
+                          hipStream_t s)
+{
+    Carver c(workspace, workspace_bytes);
+    SharedLayout L;
+    carve_shared(c, m, p, L, table16(m));
+    if (!c.ok()) return fail(AG_ERR_WS, "ag_rollout (shared state): workspace %zu < %zu bytes", workspace_bytes, c.off);
+    AgSharedArgs &sh = L.sh;
+    AgFwdArgs &f = L.f;
+    AgEdgeArgs &e = L.e;
+    const int B1 = p->B + 1, N = p->N, n_p = p->n_p, H = m->cfg.n_his, Pd = m->cfg.phys_dim;
+    const size_t plane = (size_t)N * 3;
+    sh.B1 = B1; sh.N = N; sh.n_p = n_p; sh.n_inst = p->n_instance; sh.phys_dim = Pd; sh.H = H;
+    sh.state0 = state0; sh.delta = delta; sh.attrs = attrs; sh.p_instance = p_instance; sh.phys = phys; sh.thr_sq = thr_sq;
+    sh.mask = mask; sh.tool = tool_mask; sh.obj_mask = obj_mask; sh.repeat = repeat;
+    ag_launch_shared_stage(sh, s);      // internal sample 0 = the base (caller sample 0 without its tools), 1 .. B = the caller's samples; first dirty flags
+    e.mask = sh.s_mask; e.tool = sh.s_tool; e.thr_sq = sh.s_thr; e.topk = p->topk; e.variant = AG_VARIANT_BATCH; e.max_tools = p->max_tools;
+    e.pos = sh.s_state + (size_t)(H - 1) * plane;
+    e.pos_stride = (size_t)H * plane;
+    f.state = sh.s_state; f.attrs = sh.s_attrs; f.action = sh.s_delta; f.p_instance = sh.s_pinst; f.phys = Pd > 0 ? sh.s_phys : nullptr;
+    f.row_ptr = e.row_ptr; f.edge_recv = e.edge_recv; f.edge_send = e.edge_send;
+    f.pred_pos = L.pred_pos; f.pred_motion = L.pred_motion;
+    f.B = B1; f.N = N; f.n_p = n_p; f.n_inst = p->n_instance; f.phys_dim = Pd; f.pstep = m->cfg.pstep; f.clamp = m->cfg.motion_clamp;
+    setup_args(m, f, m->max_blocks, p->n_steps);
+    f.dedup = 1;                        // the propagation rounds read the node encoder through its compact rows whatever "node_dedup" says (carve: no overflow possible)
+    f.ovf = f.tile_ctr + 3;
+    const int self_rows = m->self_edges ? AG_SELF_ROWS : 0;
+    if (self_rows) { e.self_attrs = f.attrs; e.self_class_row0 = f.self_class_row0; }
+    if (edge_ws_path(f)) {              // rider: the per-node input rows of the edge features (all B1 N nodes: the compact edges name their endpoints as nodes)
+        e.tab_state = f.state; e.tab_attrs = f.attrs; e.tab_pinst = f.p_instance; e.tab_out = f.edge_node_tab;
+        e.tab_n_inst = f.n_inst; e.tab_n_p = f.n_p; e.tab_status = f.status;
+    }
+    run_node_encode(m, f, s);           // classification + compact encoder, once per call
+    sh.row_ptr = e.row_ptr; sh.edge_send = e.edge_send; sh.self_info = self_rows ? e.self_info : nullptr; sh.node_row = f.node_row;
+    sh.self_rows = self_rows; sh.self_class_row0 = f.self_class_row0;
+    AgFwdArgs fE = f, fP = f;           // the edge encoder's and the propagation rounds' views of the compact graph
+    fE.edge_recv = sh.recv_o; fE.edge_send = sh.send_o; fE.e_count_dev = sh.n_edges; fE.remap_done = 1; fE.self_rows = self_rows;
+    fP.row_ptr = sh.row_ptr_c; fP.edge_send = sh.send_cm; fP.send_c = sh.send_r0; fP.node_row = sh.node_row_c;
+    fP.self_info = self_rows ? sh.self_info_c : nullptr; fP.self_rows = self_rows;
+    fP.n_rows_dev = sh.n_rows; fP.e_count_dev = sh.n_edges; fP.row_orig = sh.orig;
+    AgStepArgs st{};
+    st.state = sh.s_state; st.delta = sh.s_delta; st.pred_pos = L.pred_pos; st.obj_mask = obj_mask ? sh.s_obj_mask : nullptr;
+    st.repeat = sh.s_repeat; st.out_seq = out_seq; st.B = B1; st.N = N; st.n_p = n_p; st.H = H;
+    st.height_mode = p->height_mode; st.raise = p->gripper_raise; st.cmap = sh.cmap; st.dirty = sh.dirty;
+    for (int ai = 1; ai <= p->n_steps; ++ai) {
+        int riders;
+        { Timed tm(m, AG_K_EDGES, s); riders = ag_launch_build_edges(e, s); ag_launch_shared_compact(sh, s); }
+        fE.tab_done = (riders & AG_RIDER_TAB) != 0;
+        run_edge_encode(m, fE, s);
+        run_propagate(m, fP, s);
+        st.step = ai;
+        { Timed tm(m, AG_K_ROLLOUT_STEP, s); ag_launch_rollout_step(st, s); }
+    }
+    if (state_final)
+        AG_HIP(hipMemcpyAsync(state_final, sh.s_state + (size_t)H * plane, (size_t)p->B * H * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    AG_HIP(hipGetLastError());
+    return AG_OK;
+}
+
 size_t ag_rollout_workspace_bytes(const ag_rollout_params *p) { return ag_rollout_workspace_bytes_for(nullptr, p); }
-int ag_rollout_streams_for(const ag_model *m, const ag_rollout_params *p) { return m && p ? rollout_parts(p->B, rollout_want(m, p)) : 0; }
+int ag_rollout_streams_for(const ag_model *m, const ag_rollout_params *p) { return m && p ? (shared_applicable(m, p) ? 1 : rollout_parts(p->B, rollout_want(m, p))) : 0; }
 
 size_t ag_rollout_workspace_bytes_for(const ag_model *m, const ag_rollout_params *p)
 {
@@ -1039,6 +1173,12 @@ size_t ag_rollout_workspace_bytes_for(const ag_model *m, const ag_rollout_params
         }
         need = c.off > need ? c.off : need;
     }
+    if (shared_applicable(m, p)) {      // (an option the caller may switch off again before the call: the larger of the two layouts)
+        Carver c(nullptr, 0);
+        SharedLayout L;
+        carve_shared(c, m, p, L, table16(m));
+        need = c.off > need ? c.off : need;
+    }
     return align_up(need, 256);
 }
 
@@ -1055,6 +1195,9 @@ int ag_rollout(ag_model *m, const ag_rollout_params *p, const float *state0, con
         return fail(AG_ERR_ARG, "ag_rollout: bad sizes");
     if (m->cfg.phys_dim > 0 && !phys) return fail(AG_ERR_ARG, "ag_rollout: phys is null");
     hipStream_t s0 = static_cast<hipStream_t>(stream);
+    if (shared_applicable(m, p))
+        return rollout_shared(m, p, state0, delta, attrs, p_instance, phys, mask, tool_mask, obj_mask, thr_sq, repeat, out_seq, state_final, workspace,
+                              workspace_bytes, s0);
     const int H = m->cfg.n_his, N = p->N, n_p = p->n_p, Pd = m->cfg.phys_dim;
     const int parts = rollout_parts(p->B, rollout_want(m, p));
     for (int k = 1; k < parts; ++k)

@@ -118,10 +118,18 @@ struct AgFwdArgs {
     // self_info[g] = (class << 16) | position of the elided self-loop in g's row, or -1 (no self-loop, or another attribute pair: kept as a real edge);
     // row_ptr / edge_recv / edge_send then describe the graph WITHOUT the elided edges.  NULL: nothing is elided (ag_forward on a caller's CSR).
     const int32_t *self_info;
+    // ---- shared-state rollout (r06, ag_shared.hip; option "shared_state"): the propagation kernels run over a COMPACT row set — the base sample's nodes
+    // followed by every sample's private nodes — whose size only the device knows.  Non-NULL n_rows_dev / e_count_dev replace B * N / row_ptr[B * N]
+    // as the row and edge counts (B * N stays the upper bound the launches are sized by); row_orig[row] is the node (sample * N + particle) a row
+    // stands for — the decoder round needs the sample's state and writes pred_pos / pred_motion BY ROW (rows x 3) instead of by (sample, particle).
+    const int *n_rows_dev, *e_count_dev;
+    const int32_t *row_orig;
     int self_class_row0;      // row of class 0 in edge_node_tab (= the layout's rows_pad) = the node id the synthetic edges carry as receiver and sender
     int self_rows;            // synthetic class edges behind the COO list (AG_SELF_ROWS with elision, else 0): the edge encoders walk row_ptr[B N] + self_rows edges
 };
 #define AG_SELF_ROWS 2
+__device__ __forceinline__ int ag_rows(const AgFwdArgs &a) { return a.n_rows_dev ? *a.n_rows_dev : a.B * a.N; }
+__device__ __forceinline__ int ag_edges(const AgFwdArgs &a) { return a.e_count_dev ? *a.e_count_dev : a.row_ptr[a.B * a.N]; }
 // rows of the per-edge table / entries of the COO arrays for a graph of at most e_cap edges (+ the class rows), in whole 256-row tiles
 __host__ __device__ __forceinline__ size_t ag_edge_rows_pad(long long e_cap) { return ((size_t)(e_cap > 0 ? e_cap : 1) + AG_SELF_ROWS + 255) / 256 * 256; }
 // attribute class of a node for self-edge elision: 0 = (1, 0), 1 = (0, 1), -1 = anything else
@@ -189,7 +197,7 @@ __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin
 // An elided self-loop (AgFwdArgs::self_info) is a VIRTUAL edge: node g has n = (e1 - e0) + 1 of them, virtual edge j is table row / COO entry
 // e0 + j - (j > kself), except j == kself: the class row (table row E + class) and the node itself as the sender.
 struct AgSelfView {
-    int e0, n, kself, eself;
+    int e0, n, kself, eself, cls;
     __device__ __forceinline__ int row(int j) const { return j == kself ? eself : e0 + j - (j > kself ? 1 : 0); }
 };
 __device__ __forceinline__ AgSelfView ag_self_view(const AgFwdArgs &a, int g)
@@ -199,17 +207,25 @@ __device__ __forceinline__ AgSelfView ag_self_view(const AgFwdArgs &a, int g)
     v.e0 = a.row_ptr[g];
     const int si = a.self_info ? a.self_info[g] : -1;
     v.kself = si >= 0 ? (si & 0xffff) : 0x7fffffff;
-    v.eself = si >= 0 ? a.row_ptr[a.B * a.N] + (si >> 16) : 0;
+    v.cls = si >= 0 ? si >> 16 : 0;
+    v.eself = si >= 0 ? ag_edges(a) + v.cls : 0;
     v.n = e1 - v.e0 + (si >= 0 ? 1 : 0);
     return v;
 }
 
+// `self_lds`: the AG_SELF_ROWS class rows of the table staged in LDS by the calling kernel ([class][20 segments] int4), or NULL.  EVERY node reads
+// its class row: from global memory that is 256 k x 20 lanes x 3 rounds hammering the same three cache lines of one L2 channel (measured: the reduce
+// 7 % slower than without elision); from LDS it is one 640-byte fetch per workgroup.
 template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
-__device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1)
+__device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1,
+                                                   const int4 *self_lds = nullptr)
 {
     const int f0 = ag_half_lane_feature(c);
     const AgSelfView sv = ag_self_view(a, g);
     const int n = sv.n;
+    int4 tself = make_int4(0, 0, 0, 0);      // this lane's segment of the node's class row (elided self-loop)
+    if (sv.kself != 0x7fffffff)
+        tself = self_lds ? self_lds[sv.cls * (AG_FP / 8) + c] : *(reinterpret_cast<const int4 *>(a.eterm) + (size_t)sv.eself * (AG_FP / 8) + c);
     const int4 *et = reinterpret_cast<const int4 *>(a.eterm) + c;          // segment c of row e: et[e * 20]
     const float *hs = a.hs + f0;
     const int4 *hq = reinterpret_cast<const int4 *>(a.hs) + c;             // HSQ: segment c of sender row s: hq[s * 20]
@@ -234,7 +250,8 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                t[i] = ag_ld_nt(&et[(size_t)sv.row(e + i) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
+                if (e + i == sv.kself) t[i] = tself;
+                else t[i] = ag_ld_nt(&et[(size_t)(sv.e0 + e + i - (e + i > sv.kself ? 1 : 0)) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
                 if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
                 else {
                     u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
@@ -370,7 +387,11 @@ __device__ __forceinline__ void ag_edge_node_tab_row(const float *state, const f
 struct AgStepArgs {
     float *state;             // (B, H, N, 3) working copy, shifted in place
     const float *delta;       // (B, N, 3) per-step tool motion ("action")
-    const float *pred_pos;    // (B, n_p, 3)
+    const float *pred_pos;    // (B, n_p, 3); shared-state rollout: (rows, 3) by compact row, read through cmap
+    // shared-state rollout (ag_shared.hip): sample 0 is the base; a particle's prediction is row cmap[b * N + i] of pred_pos (its private row, or the
+    // base sample's row i); `dirty` turns on where a private prediction differs from the base's in any bit; samples b >= 1 record into out_seq[b - 1]
+    const int32_t *cmap;      // NULL: the plain rollout
+    uint8_t *dirty;
     const uint8_t *obj_mask;  // (B, n_p) or nullptr; used by height mode 1
     const int32_t *repeat;    // (B) action_repeat
     float *out_seq;           // (B, n_p, 3) recorded when repeat == step
@@ -378,6 +399,40 @@ struct AgStepArgs {
     float raise;              // gripper raise (0 when disabled)
 };
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s);
+
+// ---- shared-state rollout (ag_shared.hip) ------------------------------------------------------------------------------------
+// dynamics() rolls ONE cloud out under `bsz` sampled pushes (forward_dynamics.py:11-38; 20 000 samples per planning step in config/planning/rope.yaml):
+// wherever a sample's tool has not (yet) had any influence, its particles follow the trajectory of the cloud without a tool — the BASE — bit for bit.
+// The engine rolls the base out once, as internal sample 0 (the caller's sample 0 with its tool slots invalid), and per model step computes
+// privately only the rows whose result can differ: the 3-hop closure (three propagation rounds) of the rows that differ from the base in an input, an
+// edge list or a sender.  Everything per-node that is cheap stays full size (states, edge lists); the heavy kernels run over a COMPACT row set
+// [base rows | private rows of sample 1 | sample 2 ...] through index arrays built per step.
+struct AgSharedArgs {
+    int B1, N, n_p, n_inst, phys_dim, H;      // B1 = caller samples + 1
+    // caller inputs (B1 - 1 samples) and their staged copies (B1 samples; sample 0 = the base)
+    const float *state0, *delta, *attrs, *p_instance, *phys, *thr_sq;
+    const uint8_t *mask, *tool, *obj_mask;
+    const int32_t *repeat;
+    float *s_state, *s_delta, *s_attrs, *s_pinst, *s_phys, *s_thr;
+    uint8_t *s_mask, *s_tool, *s_obj_mask;
+    int32_t *s_repeat;
+    // flags per internal node
+    uint8_t *dirty;                 // sticky: an input, or an earlier prediction, of this node differs from the base's
+    uint8_t *sel_a, *sel_b;         // this step's private set while it grows (touched rows -> +1 hop -> +2 hops)
+    // this step's full graph (the edge builder over B1 samples) and the node encoder's compact rows
+    const int32_t *row_ptr, *edge_send, *self_info, *node_row;
+    // this step's compact graph
+    int32_t *cmap;                  // (B1 N) node -> compact row (private row, or the base sample's row of the same particle)
+    int32_t *orig;                  // (rows) compact row -> node
+    int32_t *row_ptr_c, *self_info_c, *node_row_c;      // (rows [+ 1])
+    int32_t *recv_o, *send_o;       // (edges) endpoints as NODES: the edge encoder's gathers of per-node inputs
+    int32_t *send_r0, *send_cm;     // (edges) sender as a row of the node encoder's compact tables (round 0) / as a compact row (later rounds)
+    int32_t *blk_cnt, *blk_deg;     // scan partials per 256 nodes
+    int *n_rows, *n_edges;          // device words: compact rows / edges of this step
+    int self_rows, self_class_row0;
+};
+void ag_launch_shared_stage(const AgSharedArgs &a, hipStream_t s);
+void ag_launch_shared_compact(const AgSharedArgs &a, hipStream_t s);
 void ag_launch_gather_rows(const float *x, const int *idx, float *out, long long E, int D, hipStream_t s);
 void ag_launch_segment_sum(const float *vals, const int *ptr, const int *perm, float *out, long long N, int D, hipStream_t s);
 void ag_launch_message_fwd(const float *eterm, const float *hr, const float *hs, const int *row_ptr, const int *send, float *agg,

@@ -978,8 +978,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
 {
     AG_LDS_DECL
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-    const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn] + a.self_rows;      // (+ the class rows of elided self-loops, AgFwdArgs::self_info: synthetic edges behind the list)
+    const int E = ag_edges(a) + a.self_rows;      // (+ the class rows of elided self-loops, AgFwdArgs::self_info: synthetic edges behind the list)
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int ntiles = (E + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     if ((int)blockIdx.x >= ntiles) return;
@@ -1408,8 +1407,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
     __shared__ __attribute__((aligned(16))) float4 s_wf[AG_CHUNK_F4];                         // first-layer fragments [5 tiles][2 steps][hi|lo][64][8]
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Mn = a.B * a.N;
-    const int E = a.row_ptr[Mn] + a.self_rows;      // (+ the class rows of elided self-loops: their endpoints are the class rows of the per-node table)
+    const int E = ag_edges(a) + a.self_rows;      // (+ the class rows of elided self-loops: their endpoints are the class rows of the per-node table)
     if (a.edge_counter && blockIdx.x == 0 && tid == 0) atomicAdd(a.edge_counter, (unsigned long long)E);
     const int nblk = (E + 31) / 32;
     if ((int)blockIdx.x >= nblk) return;
@@ -1619,7 +1617,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
     AG_LDS_DECL
     __shared__ __attribute__((aligned(16))) float stage[FUSE ? 32 * AG_STAGE_LD : 4];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-    const int Mn = a.B * a.N;
+    const int Mn = ag_rows(a);
     const int ntiles = (Mn + AG_ROWS_PER_BLOCK - 1) / AG_ROWS_PER_BLOCK;
     ChunkPipe P{LAST ? pick<Prec>(w.node_last, w.node_last_b3) : pick<Prec>(w.node_mid, w.node_mid_b3), LAST ? 16 : 15, 0, 0, lds};
     pipe_start(P);
@@ -1727,11 +1725,12 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             f32x16 m;
             Prec::template layer<AG_F, 1, false, true>(P, y, ZeroInit{}, NoEpi{},      // linear_2 -> rows 0..2 of tile 0
                                                        [&](int, const f32x16 &v) { m = v; });
-            const int b = gc / a.N, i = gc - b * a.N;
+            const int go = a.row_orig ? a.row_orig[gc] : gc;      // (shared-state rollout: the node this compact row stands for; predictions are stored by row)
+            const int b = go / a.N, i = go - b * a.N;
             if (valid && h == 0 && i < a.n_p) {
                 const float *cur = a.state + (((size_t)b * AG_NHIS + (AG_NHIS - 1)) * a.N + i) * 3;
-                float *pm = a.pred_motion + ((size_t)b * a.n_p + i) * 3;
-                float *pp = a.pred_pos + ((size_t)b * a.n_p + i) * 3;
+                float *pm = a.pred_motion + (a.row_orig ? (size_t)gc : (size_t)b * a.n_p + i) * 3;
+                float *pp = a.pred_pos + (a.row_orig ? (size_t)gc : (size_t)b * a.n_p + i) * 3;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float mv = m[c];
@@ -1840,7 +1839,7 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
     constexpr int N1 = WAVE == 3 ? 2 : 1, N2 = WAVE == 1 ? 2 : 1, N3 = WAVE == 2 ? 2 : 1;      // the fifth out-tiles: layer 1's to wave 3, Hr's to wave 1, Hs's to wave 2
     constexpr int N23 = N2 + N3;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int Mn = a.B * a.N;
+    const int Mn = ag_rows(a);
     const int nblk = (Mn + 31) / 32;
     const int n_i = ((int)blockIdx.x < nblk) ? (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const bool ovf = a.ovf && *a.ovf != 0;

@@ -19,12 +19,15 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 {
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *pred = a.pred_pos + (size_t)b * a.n_p * 3;
+    // prediction of particle i, component c: by (sample, particle), or — shared-state rollout — by compact row through cmap (a private row or the base's)
+    const float *pred = a.pred_pos + (a.cmap ? (size_t)0 : (size_t)b * a.n_p * 3);
+    const int32_t *cm = a.cmap ? a.cmap + (size_t)b * a.N : nullptr;
+    auto at = [&](int i, int c) { return pred[(size_t)(cm ? cm[i] : i) * 3 + c]; };
 
     float y;
     if (a.height_mode == 0) {
         float m = INFINITY;
-        for (int i = tid; i < a.n_p; i += 256) m = fminf(m, pred[i * 3 + 1]);
+        for (int i = tid; i < a.n_p; i += 256) m = fminf(m, at(i, 1));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
         if (lane == 0) red[wave] = m;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
         float s = 0.f, c = 0.f;
         for (int i = tid; i < a.n_p; i += 256) {
             const float w = mk[i] ? 1.f : 0.f;
-            s += pred[i * 3 + 1] * w;
+            s += at(i, 1) * w;
             c += w;
         }
 #pragma unroll
@@ -48,12 +51,16 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 
     const int plane = a.N * 3;
     const int k0 = blockIdx.y * kStepChunk, k1 = min(k0 + kStepChunk, plane);
-    if (a.repeat[b] == a.step) {
-        float *o = a.out_seq + (size_t)b * a.n_p * 3;
-        for (int k = k0 + tid; k < min(k1, a.n_p * 3); k += 256) o[k] = pred[k];
+    if (a.repeat[b] == a.step && !(cm && b == 0)) {
+        float *o = a.out_seq + (size_t)(cm ? b - 1 : b) * a.n_p * 3;      // (shared-state rollout: internal sample b is the caller's b - 1; the base records nothing)
+        for (int k = k0 + tid; k < min(k1, a.n_p * 3); k += 256) o[k] = at(k / 3, k % 3);
     }
     float *st = a.state + (size_t)b * a.H * a.N * 3;
     const float *dl = a.delta + (size_t)b * a.N * 3;
+    // shared-state rollout: a private prediction that differs from the base's in any bit makes the particle dirty from the next step on
+    auto mark = [&](int n, int c, float v) {
+        if (cm && b > 0 && cm[n] != n && __float_as_uint(v) != __float_as_uint(pred[(size_t)n * 3 + c])) a.dirty[(size_t)b * a.N + n] = 1;
+    };
     if (a.H == AG_NHIS) {
         // all of this thread's loads first, then its stores: `st` is read and written, so a plain loop orders every iteration's loads behind the
         // previous iteration's stores — eight dependent memory round trips per thread (17 us per launch at C2; 8 us this way)
@@ -66,7 +73,8 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 #pragma unroll
                 for (int h = 1; h < AG_NHIS; ++h) v[i][h] = st[(size_t)h * plane + k];
                 const int n = k / 3, c = k - n * 3;
-                nv[i] = n < a.n_p ? pred[k] : (c == 1 ? y : v[i][AG_NHIS - 1] + dl[k]);
+                nv[i] = n < a.n_p ? at(n, c) : (c == 1 ? y : v[i][AG_NHIS - 1] + dl[k]);
+                if (n < a.n_p) mark(n, c, nv[i]);
             }
         }
 #pragma unroll
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
         const float last = st[(size_t)(a.H - 1) * plane + k];
         for (int h = 0; h + 1 < a.H; ++h) st[(size_t)h * plane + k] = st[(size_t)(h + 1) * plane + k];
         float nv;
-        if (n < a.n_p) nv = pred[k];
+        if (n < a.n_p) { nv = at(n, c); mark(n, c, nv); }
         else nv = (c == 1) ? y : last + dl[k];
         st[(size_t)(a.H - 1) * plane + k] = nv;
     }

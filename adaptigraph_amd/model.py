@@ -136,7 +136,9 @@ class DynamicsPredictor(nn.Module):
         """Engine knob (include/adaptigraph_hip.h: ag_set_option): "precision" 0 = exact fp32 MFMA, 1 = split-bf16 with an
         fp32 per-edge table, 2 = split-bf16 node stacks + fp16 edge stack with residual bytes + 16-bit block-scaled per-edge
         table ("fast", the default; its fp16 activations have fp16's range, see take_status); "rollout_streams"; "node_dedup";
-        "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"; "node_stationary"; "cu_split"."""
+        "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"; "node_stationary"; "cu_split"; "self_edges" (r06: self-loops of the
+        attribute classes (1, 0) / (0, 1) as one table row per class, default 1); "shared_state" (r06: rollouts of one cloud under many sampled
+        pushes compute per sample only what can differ from the tool-less base trajectory, default 0).  All of them give the same bits."""
         dev = torch.device(device if device is not None else self.device)
         _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
         return self

@@ -502,6 +502,16 @@ def main():
             extra["bf16x3_mode"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "arithmetic": DTYPE["bf16x3"],
                                     "model_status": e["model_status"],
                                     "note": "same workload, ag_set_option(precision, 1)"}
+        if not args.no_profile:       # the SAME workload with ag_set_option("shared_state", 1): reported beside the headline, never as it (the headline is full per-sample work)
+            eng.opt("shared_state", 1)
+            e = eng.run(args.batch, T, args.precision, args.streams, max(2, args.steps // 2), 1, profile=True, tag="shared_state", keep=want_drift)
+            eng.opt("shared_state", 0)
+            ke = e["roofline"]["edges_per_launch"] if e["roofline"] else None
+            extra["shared_state"] = {"value": e["value"], "unit": "graph-steps/s", "ms_per_step": e["ms_per_step"], "model_status": e["model_status"],
+                                     "edges_per_model_step": ke, "plain_edges_per_model_step": r["roofline"]["edges_per_launch"] if r["roofline"] else None,
+                                     "equal_to_plain": bool(want_drift and np.array_equal(e["out"], r["out"])) if want_drift else None, "kernels": e["kernels"],
+                                     "note": "ag_set_option(shared_state, 1): dynamics() rolls ONE cloud out under all action samples; the tool-less base trajectory "
+                                             "is computed once and per sample only the rows that can differ from it; bit-identical results (equal_to_plain)"}
         if args.weights == "seed0":       # throughput does not depend on the weights; the numeric status must stay clean on trained ones too
             with leg("trained"):
                 et = Engine(args.material, dict(np.load(os.path.join(ROOT, "tests", "golden", "weights_trained_rope.npz"))), dev, world)
@@ -524,10 +534,14 @@ def main():
         try:        # BASELINE configs[4] on one GPU: per-iteration wall-clock of the MPPI loop (bench_mpc.py measures it at N GPUs)
             import bench_mpc
             with leg("mpc"):
-                ms_it, _ = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision)
+                ms_full, r_full = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision, shared_state=0)
+                ms_it, r_sh = bench_mpc.mppi_bench(torch.device(dev), 1000, 1024, 15, steps=3, warmup=1, precision=args.precision, shared_state=1)
             extra["mpc"] = {"workload": "MPPI iteration: 1024 sampled pushes x 15-step rollout on rope-1000, chamfer + penalty cost, softmax update "
                                         "(BASELINE configs[4], 1 GPU)", "value": ms_it, "unit": "ms per iteration", "higher_is_better": False,
-                            "graph_steps_per_s": 1024 * 15 / ms_it * 1e3, "precision": args.precision}
+                            "graph_steps_per_s": 1024 * 15 / ms_it * 1e3, "precision": args.precision,
+                            "engine_option": "shared_state 1: the 1024 pushes roll ONE cloud out — the tool-less base trajectory once, per sample only the rows that "
+                                             "can differ from it (bit-identical to the plain rollout: rewards_equal below)",
+                            "plain_rollout_ms": ms_full, "rewards_equal": bool(torch.equal(r_full, r_sh))}
         except Exception as e:      # noqa: BLE001
             extra["mpc"] = {"error": repr(e)}
 
@@ -562,7 +576,13 @@ def main():
                 cfg[f"{mat}_value"] = round(v["value"], 1)
                 cfg[f"{mat}_status"] = v["model_status"]
             if "value" in extra.get("mpc", {}):
-                cfg["mpc_ms"] = round(extra["mpc"]["value"], 2)
+                cfg["mpc_ms"] = round(extra["mpc"]["value"], 2)                       # with the shared-state rollout (bit-identical)
+                cfg["mpc_plain_ms"] = round(extra["mpc"]["plain_rollout_ms"], 2)      # every sample in full (r05: 105.7)
+                cfg["mpc_rewards_equal"] = extra["mpc"]["rewards_equal"]
+            if "shared_state" in extra:
+                cfg["shared_state_value"] = round(extra["shared_state"]["value"], 1)
+                cfg["shared_state_edges_per_step"] = extra["shared_state"]["edges_per_model_step"]
+                cfg["plain_edges_per_step"] = extra["shared_state"]["plain_edges_per_model_step"]
         if ranks:
             line["ranks"] = ranks
         if extra:

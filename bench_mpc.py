@@ -31,7 +31,8 @@ from adaptigraph_amd import _lib, configs, losses, mpc, synth          # noqa: E
 from adaptigraph_amd.model import DynamicsPredictor                    # noqa: E402
 
 
-def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1, chunk=None, streams=None, dry=False):
+def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup=2, precision="fast", world=1, chunk=None, streams=None, dry=False,
+               shared_state=0):
     """Time `steps` MPPI iterations (sample -> sharded rollout -> chamfer/penalty cost -> softmax update) on this rank's GPU.
     Returns (ms per iteration measured on this rank, last reward tensor)."""
     import time
@@ -59,6 +60,7 @@ def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup
         model = model.to(dev).eval().set_option("precision", {"f32": 0, "bf16x3": 1, "fast": 2}[precision])
         if streams is not None:
             model.set_option("rollout_streams", streams)
+        model.set_option("shared_state", shared_state)      # 1: the samples share one cloud — roll the tool-less base out once, per sample only what can differ (bit-identical)
         error = partial(losses.chamfer, y=target_t[None])
     planner = mpc.MPPIPlanner(model, dev, ppm, error,
                               partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
@@ -108,6 +110,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=None, help="evaluate the samples in chunks of this size, as the reference planner does "
                                                           "(config/planning/rope.yaml: n_sample 20000, n_sample_chunk 500); default: one rollout")
     ap.add_argument("--streams", type=int, default=None, help="rollout_streams engine option (default: the engine's choice)")
+    ap.add_argument("--shared-state", type=int, default=1, choices=[0, 1],
+                    help="engine option shared_state (default 1 here: an MPPI iteration rolls ONE cloud out under all sampled pushes — the engine rolls the "
+                         "tool-less base trajectory out once and computes per sample only the rows that can differ; same bits as 0)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU, no engine: gloo process group on CPU tensors, sampling / sharding / all-gather / MPPI "
                                                              "update and the JSON line only (contract check; the number is meaningless)")
     a = ap.parse_args()
@@ -133,7 +138,8 @@ def main():
             else:
                 dist.init_process_group(backend)
         _lib.lib()
-    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world, a.chunk, a.streams, dry=a.dry_run)
+    per_it, _ = mppi_bench(dev, a.particles, a.samples, a.push_steps, a.steps, a.warmup, a.precision, world, a.chunk, a.streams, dry=a.dry_run,
+                           shared_state=a.shared_state)
     tt = torch.tensor([per_it], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -148,7 +154,8 @@ def main():
             "graph_steps_per_s": round(a.samples * a.push_steps / per_it * 1e3, 1),
             "config": {"workload": f"rope-{a.particles}+1 MPPI: {a.samples} samples x {a.push_steps}-step rollout, chamfer "
                                    f"cost to a {a.particles}-point target", "samples": a.samples, "push_steps": a.push_steps,
-                       "particles": a.particles, "parallelism": f"samples/{world}", "sample_chunk": a.chunk, "rollout_streams": a.streams}}))
+                       "particles": a.particles, "parallelism": f"samples/{world}", "sample_chunk": a.chunk, "rollout_streams": a.streams,
+                       "shared_state": a.shared_state}}))
     if world > 1:
         dist.destroy_process_group()
 

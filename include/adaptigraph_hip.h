@@ -81,6 +81,16 @@ int ag_model_destroy(ag_model *m);
  *                            nothing else — one table row per class is encoded instead and the segment reduce adds it at the self-loop's position
  *                            in the receiver's order (10 % / 17 % / 5 % fewer rows at rope-1k / cloth-4k / granular-2k); other attribute pairs keep
  *                            their self-loops as real edges.  0 = every edge through the pipeline.  Bit-identical results
+ *   "shared_state"     0/1   ag_rollout: 1 = exploit that dynamics() rolls ONE cloud out under `B` sampled pushes (forward_dynamics.py:11-38;
+ *                            config/planning/rope.yaml:39-42: 20 000 samples per planning step).  The trajectory of the cloud WITHOUT a tool (the caller's
+ *                            sample 0 with its tool slots invalid) is rolled out once as an extra internal sample; per model step every sample's full edge
+ *                            lists are still built, but the encoders and the propagation rounds run only over the rows whose result can differ from the
+ *                            base's — nodes whose inputs or earlier predictions differ in any bit (tool slots always), rows whose edge list differs from
+ *                            the base's, and their 3-hop closure (three propagation rounds) — and every other particle takes the base's prediction.
+ *                            Results equal the plain rollout bit for bit for ANY input (samples whose states differ from sample 0's are simply all
+ *                            private); one stream, node de-duplication forced on, workspace of ag_rollout_workspace_bytes_for(model, ...) with the option
+ *                            set.  0 (default) = every sample in full — what the headline benchmark is quoted on.  Not combined with
+ *                            "fuse_aggregate" 2 / "cu_split" (those calls take the plain path)
  *   "cu_split"         0|8k  CU-partitioned rollout (off by default): the first `cu_split` CU-mask bits (cu_split / 8 CUs of every XCD) run the
  *                            MFMA-bound edge encoder, the other CUs the HBM-bound edge build / segment reduce / node update / state step, the batch
  *                            parts pipelined through the two partitions on two CU-masked queues (hipExtStreamCreateWithCUMask).  Bit-identical

@@ -516,6 +516,91 @@ def test_self_edge_elision_keeps_other_attribute_pairs_and_duplicate_particles(w
     assert m.take_status() == 0
 
 
+@pytest.mark.parametrize("mode,material,n_obj,batch,steps", [
+    ("fast", "rope", 1000, 96, 6), ("bf16x3", "rope", 1000, 40, 4), ("f32", "rope", 300, 33, 5), ("fast", "granular", 2000, 12, 3),
+    ("fast", "cloth", 1024, 9, 4), ("fast", "rope", 100, 7, 4)])
+def test_shared_state_rollout_is_bitwise_the_plain_rollout(weights, mode, material, n_obj, batch, steps):
+    """ag_set_option("shared_state", 1) (r06): dynamics() rolls ONE cloud out under `batch` sampled pushes, so the engine rolls the tool-less base
+    trajectory out once and computes per sample only the rows that can differ from it (dirty nodes, rows with another edge list or a dirty sender,
+    3-hop closure per model step); every other particle takes the base's prediction.  Same bits as the plain rollout — state_seqs of dynamics() in
+    every arithmetic mode, with and without self-edge elision, the streaming kernels, a multi-step look-ahead (per-sample states from the second
+    look-ahead step on: everything private), connect_tools_all (cloth: a touching tool makes the whole sample private)."""
+    m = make_model(weights, material, prec=mode)
+    kw = dict(spacing=0.1) if material == "rope" else {}
+    state, act = synth.make_mpc_inputs(material, n_obj, batch, n_look=2 if n_obj <= 300 else 1, seed=13, len_lo=steps, len_hi=steps + 0.9, **kw)
+
+    def run():
+        return dynamics(t(state), t(act), m, DEV, _ppm(material))["state_seqs"].clone()
+
+    ref = run()
+    m.set_option("shared_state", 1)
+    for _ in range(2):
+        assert torch.isfinite(ref).all() and torch.equal(ref, run())
+    for name, val, back in [("self_edges", 0, 1), ("node_stationary", 0, 1), ("node_dedup", 0, 1)] + ([("edge_stationary", 0, 1)] if mode == "fast" else []):
+        m.set_option(name, val)
+        assert torch.equal(ref, run()), name
+        m.set_option(name, back)
+    assert m.take_status() == 0
+
+
+def test_shared_state_rollout_with_distinct_states_degrades_to_the_plain_rollout(weights):
+    """Per-sample DISTINCT states (dynamics_masked: every sample its own cloud and mask; and ag_rollout with perturbed per-sample inputs): nothing can be
+    shared — every node is dirty from the first step on and the option reduces to the plain rollout plus one base sample.  Same bits.  Partially
+    shared inputs too: half of the samples share sample 0's cloud, a quarter have another physics parameter, some a displaced particle."""
+    m = make_model(weights, "rope", prec="fast")
+    rng = np.random.default_rng(6)
+    state, act = synth.make_mpc_inputs("rope", 400, 12, seed=5, len_lo=4, len_hi=4.9, spacing=0.1)
+    st = np.repeat(state[None], 12, 0) + rng.normal(0, 0.002, (12,) + state.shape).astype(np.float32)
+    sm = rng.uniform(size=(12, 400)) < 0.85
+    ref = dynamics_masked(t(st), t(sm), t(act[:, 0]), m, DEV, _ppm("rope"))["state_seqs"].clone()
+    m.set_option("shared_state", 1)
+    assert torch.equal(ref, dynamics_masked(t(st), t(sm), t(act[:, 0]), m, DEV, _ppm("rope"))["state_seqs"])
+    m.set_option("shared_state", 0)
+    B = 16
+    g = synth.make_graph_inputs("rope", 600, B, seed=9, spacing=0.1)
+    g["state"][:] = g["state"][:1]                                   # one cloud ...
+    g["state"][B // 2:, :, :600] += rng.normal(0, 0.003, (B - B // 2, 4, 600, 3)).astype(np.float32)      # ... but half of the samples have their own
+    g["state"][3, :, 77] += 0.05                                     # one displaced particle
+    g["state"][:, :, 600:] += rng.normal(0, 0.3, (B, 1, 1, 3)).astype(np.float32)                         # every sample its own tool position
+    g["phys"][B // 4:B // 2] = 0.8
+    g["action"][:, 600:] = rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32)
+    thr = aggraph.threshold_sq(0.5, B, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    rep = t(rng.integers(1, 6, B).astype(np.int32))
+
+    def run():
+        return tuple(x.clone() for x in rollout(m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]),
+                                                t(g["tool_mask"]), thr, rep, 5, 10, False, 1, return_state=True))
+
+    ref = run()
+    m.set_option("shared_state", 1)
+    got = run()
+    assert all(torch.isfinite(a).all() and torch.equal(a, b) for a, b in zip(got, ref))
+    assert m.take_status() == 0
+
+
+def test_shared_state_rollout_at_the_mpc_shape_computes_a_fraction_of_the_edges(weights):
+    """BASELINE configs[4] on one GPU (rope-1000 + tool, 1 024 sampled pushes x 15 model steps): bit-equal to the plain rollout, and the edge encoder
+    walks a small fraction of the plain rollout's edges (the library's per-launch edge counter): most samples' tools never touch the rope."""
+    import ctypes
+    m = make_model(weights, "rope", prec="fast")
+    state, act = synth.make_mpc_inputs("rope", 1000, 1024, seed=0, len_lo=15, len_hi=15.4, spacing=0.1)
+    L, h = _lib.lib(), m.handle(torch.device(DEV))
+
+    def run():
+        _lib.check(L.ag_profile_enable(h, 1), "ag_profile_enable")
+        out = dynamics(t(state), t(act), m, DEV, _ppm("rope"))["state_seqs"].clone()
+        ms, cnt, edges = (ctypes.c_double * 6)(), (ctypes.c_int64 * 6)(), ctypes.c_int64()
+        _lib.check(L.ag_profile_read(h, ms, cnt, ctypes.byref(edges)), "ag_profile_read")
+        _lib.check(L.ag_profile_enable(h, 0), "ag_profile_enable")
+        return out, edges.value
+
+    ref, e_full = run()
+    m.set_option("shared_state", 1)
+    got, e_shared = run()
+    assert torch.equal(ref, got) and m.take_status() == 0
+    assert 0 < e_shared < 0.25 * e_full, (e_shared, e_full)
+
+
 @pytest.mark.parametrize("mode", ["fast", "bf16x3"])
 @pytest.mark.parametrize("node_ws", [1, 0])
 def test_stale_workspace_bytes_never_reach_the_results_or_the_status(weights, mode, node_ws):
