@@ -127,7 +127,9 @@ struct AgFwdArgs {
     int self_class_row0;      // row of class 0 in edge_node_tab (= the layout's rows_pad) = the node id the synthetic edges carry as receiver and sender
     int self_rows;            // synthetic class edges behind the COO list (AG_SELF_ROWS with elision, else 0): the edge encoders walk row_ptr[B N] + self_rows edges
 };
-#define AG_SELF_ROWS 2
+#define AG_SELF_CLASSES 2
+#define AG_SELF_REPL 32            // copies of each class row in the per-edge table: every node reads one (by node id), so that 256 k nodes do not hammer one cache line
+#define AG_SELF_ROWS (AG_SELF_CLASSES * AG_SELF_REPL)
 __device__ __forceinline__ int ag_rows(const AgFwdArgs &a) { return a.n_rows_dev ? *a.n_rows_dev : a.B * a.N; }
 __device__ __forceinline__ int ag_edges(const AgFwdArgs &a) { return a.e_count_dev ? *a.e_count_dev : a.row_ptr[a.B * a.N]; }
 // rows of the per-edge table / entries of the COO arrays for a graph of at most e_cap edges (+ the class rows), in whole 256-row tiles
@@ -196,47 +198,50 @@ __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin
 
 // An elided self-loop (AgFwdArgs::self_info) is a VIRTUAL edge: node g has n = (e1 - e0) + 1 of them, virtual edge j is table row / COO entry
 // e0 + j - (j > kself), except j == kself: the class row (table row E + class) and the node itself as the sender.
-struct AgSelfView {
-    int e0, n, kself, eself, cls;
-    __device__ __forceinline__ int row(int j) const { return j == kself ? eself : e0 + j - (j > kself ? 1 : 0); }
-};
-__device__ __forceinline__ AgSelfView ag_self_view(const AgFwdArgs &a, int g)
-{
-    AgSelfView v;
-    const int e1 = a.row_ptr[g + 1];
-    v.e0 = a.row_ptr[g];
-    const int si = a.self_info ? a.self_info[g] : -1;
-    v.kself = si >= 0 ? (si & 0xffff) : 0x7fffffff;
-    v.cls = si >= 0 ? si >> 16 : 0;
-    v.eself = si >= 0 ? ag_edges(a) + v.cls : 0;
-    v.n = e1 - v.e0 + (si >= 0 ? 1 : 0);
-    return v;
-}
-
-// `self_lds`: the AG_SELF_ROWS class rows of the table staged in LDS by the calling kernel ([class][20 segments] int4), or NULL.  EVERY node reads
-// its class row: from global memory that is 256 k x 20 lanes x 3 rounds hammering the same three cache lines of one L2 channel (measured: the reduce
-// 7 % slower than without elision); from LDS it is one 640-byte fetch per workgroup.
-template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false>
-__device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1,
-                                                   const int4 *self_lds = nullptr)
+//
+// SELF (compile time: the kernels are instantiated with and without elision — a run-time `self_info ? ... : ...` is a wave-uniform BRANCH around a
+// load, and hipcc answers every such join with a vmcnt(0): the four prologue loads of the reduce ran one after the other, 0.208 -> 0.232 ms per launch):
+// `E` = number of real edges; class k's row stands AG_SELF_REPL times in the table (rows E + k AG_SELF_REPL + r) and a node reads copy r = node id mod
+// AG_SELF_REPL with the same load as any other row — EVERY node reads a class row, and one copy would be 256 k x 20 lanes x 3 rounds on the same three
+// cache lines.  (Staging the class rows in LDS — per workgroup behind a barrier, or per wave without one — and selecting them into the self slot
+// measured 3-6 % SLOWER than no elision at all: eight v_cndmask per slot in a kernel that is also VALU-heavy; profiles/r06_self_edges.txt.)  The sender
+// indices of the SELF variant are loaded UNCONDITIONALLY from a clamped position and selected afterwards (a load under `j < n && j != kself` is sunk
+// into a branch and waited for on the spot).
+template <int kInFlight = AG_AGG_IN_FLIGHT, bool HSQ = false, bool SELF = false>
+__device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, int c, int group_lane0, float4 &acc0, float4 &acc1, int E = 0)
 {
     const int f0 = ag_half_lane_feature(c);
-    const AgSelfView sv = ag_self_view(a, g);
-    const int n = sv.n;
-    int4 tself = make_int4(0, 0, 0, 0);      // this lane's segment of the node's class row (elided self-loop)
-    if (sv.kself != 0x7fffffff)
-        tself = self_lds ? self_lds[sv.cls * (AG_FP / 8) + c] : *(reinterpret_cast<const int4 *>(a.eterm) + (size_t)sv.eself * (AG_FP / 8) + c);
+    const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
+    int n = e1 - e0, kself = 0x7fffffff, eself = 0;
+    const int elast = E > 0 ? E - 1 : 0;
+    if constexpr (SELF) {
+        const int si = a.self_info[g];
+        kself = si >= 0 ? (si & 0xffff) : 0x7fffffff;
+        n += si >= 0 ? 1 : 0;
+        eself = E + (si >= 0 ? si >> 16 : 0) * AG_SELF_REPL + (g & (AG_SELF_REPL - 1));      // this node's copy of its class row
+    }
     const int4 *et = reinterpret_cast<const int4 *>(a.eterm) + c;          // segment c of row e: et[e * 20]
     const float *hs = a.hs + f0;
     const int4 *hq = reinterpret_cast<const int4 *>(a.hs) + c;             // HSQ: segment c of sender row s: hq[s * 20]
     const int exp_src = (group_lane0 + (c < 16 ? 17 : 19)) << 2;           // ds_bpermute byte address of the lane that loaded the exponent bytes
     const int exp_shift = c < 16 ? 8 * (c >> 2) : 0;
     const size_t gr = a.hr_row ? (size_t)a.hr_row[g] : (size_t)g;      // (round 0 with node de-duplication: the node's compact row)
-    // sender of virtual edge j: the COO entry, or the node itself (in the numbering edge_send uses: its own Hr row index) for the elided self-loop
-    auto sender = [&](int j) { return j < n ? (j == sv.kself ? (int)gr : a.edge_send[sv.row(j)]) : -1; };
+    // COO position of virtual edge j (any j: clamped into the array), its table row, and its sender from the raw COO entry: the node itself (in the
+    // numbering edge_send uses: its own Hr row index) for the elided self-loop
+    auto pos = [&](int j) { return SELF ? min(e0 + j - (j > kself ? 1 : 0), elast) : e0 + j; };
+    auto trow = [&](int j) { return (SELF && j == kself) ? eself : pos(j); };
+    auto pick = [&](int j, int raw) { return j < n ? ((SELF && j == kself) ? (int)gr : raw) : -1; };
     int s[kInFlight];
+    if constexpr (SELF) {
+        int raw[kInFlight];
 #pragma unroll
-    for (int i = 0; i < kInFlight; ++i) s[i] = sender(i);
+        for (int i = 0; i < kInFlight; ++i) raw[i] = a.edge_send[pos(i)];
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i) { asm volatile("" : "+v"(raw[i])); s[i] = pick(i, raw[i]); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kInFlight; ++i) s[i] = e0 + i < e1 ? a.edge_send[e0 + i] : -1;
+    }
     const float4 hr0 = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + f0);
     const float4 hr1 = *reinterpret_cast<const float4 *>(a.hr + gr * AG_FP + f0 + 8);
     acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -244,14 +249,16 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
     for (int e = 0; e < n; e += kInFlight) {       // n and with it every branch below are uniform over the node's 20 lanes
         int sn[kInFlight];
 #pragma unroll
-        for (int i = 0; i < kInFlight; ++i) sn[i] = sender(e + kInFlight + i);
+        for (int i = 0; i < kInFlight; ++i) {
+            if constexpr (SELF) sn[i] = a.edge_send[pos(e + kInFlight + i)];      // raw; selected at the end of the trip
+            else sn[i] = e0 + e + kInFlight + i < e1 ? a.edge_send[e0 + e + kInFlight + i] : -1;
+        }
         int4 t[kInFlight], v[HSQ ? kInFlight : 1];
         float4 u0[HSQ ? 1 : kInFlight], u1[HSQ ? 1 : kInFlight];
 #pragma unroll
         for (int i = 0; i < kInFlight; ++i)
             if (s[i] >= 0) {
-                if (e + i == sv.kself) t[i] = tself;
-                else t[i] = ag_ld_nt(&et[(size_t)(sv.e0 + e + i - (e + i > sv.kself ? 1 : 0)) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
+                t[i] = ag_ld_nt(&et[(size_t)trow(e + i) * (AG_FP / 8)]);      // (round 0 included: plain loads of the table the edge encoder has just written measured +2 %)
                 if constexpr (HSQ) v[i] = hq[(size_t)s[i] * (AG_FP / 8)];
                 else {
                     u0[i] = *reinterpret_cast<const float4 *>(hs + (size_t)s[i] * AG_FP);
@@ -282,7 +289,10 @@ __device__ __forceinline__ void ag_reduce_node_q16(const AgFwdArgs &a, int g, in
                 }
             }
 #pragma unroll
-        for (int i = 0; i < kInFlight; ++i) s[i] = sn[i];
+        for (int i = 0; i < kInFlight; ++i) {
+            if constexpr (SELF) { asm volatile("" : "+v"(sn[i])); s[i] = pick(e + kInFlight + i, sn[i]); }
+            else s[i] = sn[i];
+        }
     }
     // the padding positions (features 150..159) decoded the exponent bytes: they are not features
     if (c == 17) acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -350,7 +360,7 @@ int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns t
 __device__ __forceinline__ void ag_edge_node_tab_row(const float *state, const float *attrs, const float *p_instance, int n_inst, int n_p,
                                                      int B, int N, float *tab, int *status, int g, long long class_row0 = -1)
 {
-    if (class_row0 >= 0 && g < AG_SELF_ROWS) {
+    if (class_row0 >= 0 && g < AG_SELF_CLASSES) {
         float4 *dst = reinterpret_cast<float4 *>(tab + (size_t)(class_row0 + g) * 16);
         dst[0] = make_float4(g == 0 ? 1.0f : 0.0f, g == 0 ? 0.0f : 1.0f, 0.0f, 0.0f);
         dst[1] = dst[2] = dst[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
     if (r < rows) a.row_ptr[r] = off;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.row_ptr[rows] = base + total;
     if (a.self_attrs && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < AG_SELF_ROWS) {      // the class rows' synthetic edges, behind the list
-        a.edge_recv[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x;
-        a.edge_send[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x;
+        a.edge_recv[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x / AG_SELF_REPL;      // (AG_SELF_REPL copies per class)
+        a.edge_send[base + total + threadIdx.x] = a.self_class_row0 + (int)threadIdx.x / AG_SELF_REPL;
     }
     __syncthreads();
     const int row0 = blockIdx.x * kScanRows;

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, (kEdgeWgPerCu<Prec>)) void edge_enc
         const bool valid = e < E;
         int r = valid ? a.edge_recv[e] : 0, s = valid ? a.edge_send[e] : 0;
         // synthetic self-edge of attribute class r - class_row0 (self-edge elision): [a, a, 0, 0 ...] — a real self-loop's inputs (x - x = +0)
-        const int cls = (a.self_rows && r >= a.self_class_row0) ? r - a.self_class_row0 : -1;
+        const int cls = (a.self_rows && r >= a.self_class_row0) ? r - a.self_class_row0 : -1;      // (every copy of a class row carries the class's node-table row)
         if (cls >= 0) r = s = 0;
         const int b = r / a.N, ri = r - b * a.N, si = s - b * a.N;
 
@@ -1654,8 +1654,14 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                         const int gn = tile * AG_ROWS_PER_BLOCK + grp * 32 + r;
                         float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
                         if (gn < Mn) {
-                            if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
-                            else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                            const int E_ = ar.self_info ? ag_edges(ar) : 0;
+                            if (ar.self_info) {
+                                if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true, true>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1, E_);
+                                else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false, true>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1, E_);
+                            } else {
+                                if (a.hs_q16) ag_reduce_node_q16<AG_AGG_IN_FLIGHT, true, false>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                                else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false, false>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
+                            }
                         }
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void shared_offsets_kernel(AgSharedArgs a, con
         *a.n_rows = rows;
         *a.n_edges = edges;
         a.row_ptr_c[rows] = edges;
-        for (int k = 0; k < a.self_rows; ++k) a.recv_o[edges + k] = a.send_o[edges + k] = a.self_class_row0 + k;      // the class rows' synthetic edges
+        for (int k = 0; k < a.self_rows; ++k) a.recv_o[edges + k] = a.send_o[edges + k] = a.self_class_row0 + k / AG_SELF_REPL;      // the class rows' synthetic edges
     }
 }
 
