@@ -1062,6 +1062,8 @@ static void carve_shared(Carver &c, const ag_model *m, const ag_rollout_params *
     s.dirty = c.take<uint8_t>(rows);
     s.sel_a = c.take<uint8_t>(rows);
     s.sel_b = c.take<uint8_t>(rows);
+    s.sample_dirty = c.take<int32_t>(B1);
+    s.active = c.take<int32_t>(B1);
     s.cmap = c.take<int32_t>(rows);
     s.orig = c.take<int32_t>(rows);
     s.row_ptr_c = c.take<int32_t>(rows + 1);
@@ -1107,10 +1109,12 @@ static int rollout_shared(ag_model *m, const ag_rollout_params *p, const float *
     sh.B1 = B1; sh.N = N; sh.n_p = n_p; sh.n_inst = p->n_instance; sh.phys_dim = Pd; sh.H = H;
     sh.state0 = state0; sh.delta = delta; sh.attrs = attrs; sh.p_instance = p_instance; sh.phys = phys; sh.thr_sq = thr_sq;
     sh.mask = mask; sh.tool = tool_mask; sh.obj_mask = obj_mask; sh.repeat = repeat;
+    sh.max_tools = p->max_tools;
     ag_launch_shared_stage(sh, s);      // internal sample 0 = the base (caller sample 0 without its tools), 1 .. B = the caller's samples; first dirty flags
     e.mask = sh.s_mask; e.tool = sh.s_tool; e.thr_sq = sh.s_thr; e.topk = p->topk; e.variant = AG_VARIANT_BATCH; e.max_tools = p->max_tools;
     e.pos = sh.s_state + (size_t)(H - 1) * plane;
     e.pos_stride = (size_t)H * plane;
+    e.active = sh.active;
     f.state = sh.s_state; f.attrs = sh.s_attrs; f.action = sh.s_delta; f.p_instance = sh.s_pinst; f.phys = Pd > 0 ? sh.s_phys : nullptr;
     f.row_ptr = e.row_ptr; f.edge_recv = e.edge_recv; f.edge_send = e.edge_send;
     f.pred_pos = L.pred_pos; f.pred_motion = L.pred_motion;
@@ -1135,10 +1139,10 @@ static int rollout_shared(ag_model *m, const ag_rollout_params *p, const float *
     AgStepArgs st{};
     st.state = sh.s_state; st.delta = sh.s_delta; st.pred_pos = L.pred_pos; st.obj_mask = obj_mask ? sh.s_obj_mask : nullptr;
     st.repeat = sh.s_repeat; st.out_seq = out_seq; st.B = B1; st.N = N; st.n_p = n_p; st.H = H;
-    st.height_mode = p->height_mode; st.raise = p->gripper_raise; st.cmap = sh.cmap; st.dirty = sh.dirty;
+    st.height_mode = p->height_mode; st.raise = p->gripper_raise; st.cmap = sh.cmap; st.dirty = sh.dirty; st.sample_dirty = sh.sample_dirty;
     for (int ai = 1; ai <= p->n_steps; ++ai) {
         int riders;
-        { Timed tm(m, AG_K_EDGES, s); riders = ag_launch_build_edges(e, s); ag_launch_shared_compact(sh, s); }
+        { Timed tm(m, AG_K_EDGES, s); ag_launch_shared_active(sh, s); riders = ag_launch_build_edges(e, s); ag_launch_shared_compact(sh, s); }
         fE.tab_done = (riders & AG_RIDER_TAB) != 0;
         run_edge_encode(m, fE, s);
         run_propagate(m, fP, s);

@@ -347,6 +347,9 @@ struct AgEdgeArgs {
     int32_t *self_info;                               // (B*N) out
     int32_t *self_pos;                                // (B*N) workspace: position of the elidable self-loop in the row, or -1 (scan_partial -> rowptr_scatter)
     int self_class_row0;                              // node-table row of class 0 (= rows_pad of the forward layout)
+    // Shared-state rollout (ag_shared.hip): samples whose `active` word is 0 this step — no dirty particle, no tool within the radius of any particle:
+    // their graph IS the base sample's — are skipped by every launch of the builder (their rows get degree 0, their per-node input rows are not written).
+    const int32_t *active;                            // (B); NULL: every sample
 };
 enum { AG_RIDER_TAB = 1, AG_RIDER_MAP = 2 };
 int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s);      // returns the riders its launches carried (AG_RIDER_*)
@@ -402,6 +405,7 @@ struct AgStepArgs {
     // base sample's row i); `dirty` turns on where a private prediction differs from the base's in any bit; samples b >= 1 record into out_seq[b - 1]
     const int32_t *cmap;      // NULL: the plain rollout
     uint8_t *dirty;
+    int32_t *sample_dirty;    // (B) set with `dirty`
     const uint8_t *obj_mask;  // (B, n_p) or nullptr; used by height mode 1
     const int32_t *repeat;    // (B) action_repeat
     float *out_seq;           // (B, n_p, 3) recorded when repeat == step
@@ -429,6 +433,9 @@ struct AgSharedArgs {
     // flags per internal node
     uint8_t *dirty;                 // sticky: an input, or an earlier prediction, of this node differs from the base's
     uint8_t *sel_a, *sel_b;         // this step's private set while it grows (touched rows -> +1 hop -> +2 hops)
+    int32_t *sample_dirty;          // (B1) sticky: some NON-tool node of the sample is dirty
+    int32_t *active;                // (B1) this step: the sample can differ from the base at all (sample_dirty, or a tool within the radius of a particle)
+    int max_tools;
     // this step's full graph (the edge builder over B1 samples) and the node encoder's compact rows
     const int32_t *row_ptr, *edge_send, *self_info, *node_row;
     // this step's compact graph
@@ -442,7 +449,8 @@ struct AgSharedArgs {
     int self_rows, self_class_row0;
 };
 void ag_launch_shared_stage(const AgSharedArgs &a, hipStream_t s);
-void ag_launch_shared_compact(const AgSharedArgs &a, hipStream_t s);
+void ag_launch_shared_active(const AgSharedArgs &a, hipStream_t s);      // before the step's edge build
+void ag_launch_shared_compact(const AgSharedArgs &a, hipStream_t s);     // behind it
 void ag_launch_gather_rows(const float *x, const int *idx, float *out, long long E, int D, hipStream_t s);
 void ag_launch_segment_sum(const float *vals, const int *ptr, const int *perm, float *out, long long N, int D, hipStream_t s);
 void ag_launch_message_fwd(const float *eterm, const float *hr, const float *hs, const int *row_ptr, const int *send, float *agg,

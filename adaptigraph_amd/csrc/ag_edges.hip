@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void select_kernel(AgEdgeArgs a)
     // then per-wave candidate lists.  Every receiver row of the block re-reads it N/64 times.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.y, N = a.N;
+    if (a.active && !a.active[b]) return;      // (shared-state rollout: this sample's graph is the base sample's)
     const int Np = (N + 63) & ~63;
     float *sx = reinterpret_cast<float *>(smem), *sy = sx + Np, *sz = sy + Np;
     unsigned char *sf = reinterpret_cast<unsigned char *>(sz + Np);          // bit0 = mask, bit1 = tool
@@ -179,10 +180,13 @@ __global__ __launch_bounds__(256) void bin_kernel(AgEdgeArgs a)
     __shared__ float red[6][4];
     __shared__ GridParams G;
     if ((int)blockIdx.x >= a.B) {       // rider workgroups (ag_rollout): the model step's per-node input rows of the edge features, a function of the state only
-        ag_edge_node_tab_row(a.tab_state, a.tab_attrs, a.tab_pinst, a.tab_n_inst, a.tab_n_p, a.B, a.N, a.tab_out, a.tab_status,
-                             ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x, a.self_attrs ? (long long)a.self_class_row0 : -1);
+        const int gt = ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x;
+        if (a.active && gt < a.B * a.N && !a.active[gt / a.N]) return;      // (no private edge names a node of an inactive sample)
+        ag_edge_node_tab_row(a.tab_state, a.tab_attrs, a.tab_pinst, a.tab_n_inst, a.tab_n_p, a.B, a.N, a.tab_out, a.tab_status, gt,
+                             a.self_attrs ? (long long)a.self_class_row0 : -1);
         return;
     }
+    if (a.active && !a.active[blockIdx.x]) return;
     const int b = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *pos = a.pos + (size_t)b * a.pos_stride;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(256) void select_cells_kernel(AgEdgeArgs a)
     __shared__ float s_d[4][kCand];
     __shared__ int s_j[4][kCand];
     const int b = blockIdx.y, N = a.N;
+    if (a.active && !a.active[b]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *cd = s_d[wave];
     int *cj = s_j[wave];
@@ -431,6 +436,7 @@ template <int K>
 __global__ __launch_bounds__(256) void select_lanes_kernel(AgEdgeArgs a)
 {
     const int b = blockIdx.y, N = a.N;
+    if (a.active && !a.active[b]) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float *pos = a.pos + (size_t)b * a.pos_stride;
@@ -477,6 +483,7 @@ template <int K>
 __global__ __launch_bounds__(256, 4) void select_lanes_packed_kernel(AgEdgeArgs a, int jb)
 {
     const int b = blockIdx.y, N = a.N;
+    if (a.active && !a.active[b]) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
     if (t < N && !mk[t]) a.deg[(size_t)b * N + t] = 0;            // receivers that were not binned have no edges
@@ -586,6 +593,7 @@ __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
     __shared__ int wcount[4];
     __shared__ int kept[256 * kKeepFast];           // per-thread list of the kept NON-tool senders (fast path: top-k <= kKeepFast)
     const int b = blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.active && !a.active[b]) return;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
     // the tool flags of the sample, all of a thread's loads in flight together (N <= 256 * kFlagK; beyond that they are read in the loop)
     constexpr int kFlagK = 17;
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(256) void finalize_connect_kernel(AgEdgeArgs a)
 __global__ __launch_bounds__(256) void finalize_connect_sweep_kernel(AgEdgeArgs a)
 {
     const int b = blockIdx.y, N = a.N;
+    if (a.active && !a.active[b]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *mk = a.mask + (size_t)b * N, *tl = a.tool + (size_t)b * N;
     const int i = blockIdx.x * 4 + wave;
@@ -758,12 +767,28 @@ __device__ __forceinline__ int self_position(const AgEdgeArgs &a, const int32_t 
 }
 constexpr int kSelfStageMax = 256 * 40;      // ints of LDS for the staged rows; rows longer than 40 slots (top-k + tools) are read from global memory
 
+// shared-state rollout: does any of the 256 rows of this block belong to an active sample?  (NULL `active`: yes)
+// `with_prev`: ... or the row in front of the block (rowptr_scatter_kernel: row_ptr[row0] is also the END of that row)
+__device__ __forceinline__ bool block_rows_active(const AgEdgeArgs &a, int row0, int rows, bool with_prev = false)
+{
+    if (!a.active) return true;
+    const int last = (row0 + kScanRows <= rows ? row0 + kScanRows : rows) - 1;
+    for (int b = (with_prev && row0 > 0 ? row0 - 1 : row0) / a.N; b <= last / a.N; ++b)
+        if (a.active[b]) return true;
+    return false;
+}
+
 __global__ __launch_bounds__(256) void scan_partial_kernel(AgEdgeArgs a, const int32_t *sel, int cap)
 {
     __shared__ int stage[kSelfStageMax];
     const int rows = a.B * a.N;
+    if (!block_rows_active(a, blockIdx.x * kScanRows, rows)) {      // (uniform) nothing to count: no row is read
+        if (threadIdx.x == 0) a.blk_sum[blockIdx.x] = 0;
+        return;
+    }
     const int r = blockIdx.x * kScanRows + threadIdx.x;
     int d = r < rows ? a.deg[r] : 0;
+    if (a.active && r < rows && !a.active[r / a.N]) d = 0;      // (shared-state rollout: skipped sample)
     if (a.self_attrs) {
         const int row0 = blockIdx.x * kScanRows, nloc = rows - row0 < kScanRows ? rows - row0 : kScanRows;
         int pos = -1;
@@ -789,6 +814,7 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
 {
     __shared__ int s_ptr[kScanRows], s_deg[kScanRows], s_self[kScanRows];
     const int rows = a.B * a.N;
+    if (blockIdx.x != gridDim.x - 1 && !block_rows_active(a, blockIdx.x * kScanRows, rows, true)) return;      // (uniform; the last block also writes the totals)
     // rider (ag_rollout, de-duplicated node encoder): the sender column mapped to compact rows for round 0's reduce, written where edge_send is.
     // (The overflow word is read here, with the partial sums, not in front of the loop that uses it: one memory round trip less on the chain.)
     const bool map = a.map_send_c != nullptr;
@@ -798,9 +824,10 @@ __global__ __launch_bounds__(256) void rowptr_scatter_kernel(AgEdgeArgs a, const
     int base;
     block_exclusive_scan(part, &base);
     const int r = blockIdx.x * kScanRows + threadIdx.x;
-    const int d = r < rows ? a.deg[r] : 0;
+    const bool live = r < rows && !(a.active && !a.active[r / a.N]);      // (rows of a skipped sample: degree 0, nothing of theirs is read — not even self_pos,
+    const int d = live ? a.deg[r] : 0;                                    //  which the degree scan's early-exit blocks never wrote)
     // self-edge elision: the row's self-loop (slot ks) is not stored; self_info tells the segment reduce where it belongs
-    const int ks = (a.self_attrs && r < rows) ? a.self_pos[r] : -1;
+    const int ks = (a.self_attrs && live) ? a.self_pos[r] : -1;
     if (a.self_attrs && r < rows)
         a.self_info[r] = ks >= 0 ? ((ag_self_class(a.self_attrs[(size_t)r * 2], a.self_attrs[(size_t)r * 2 + 1]) << 16) | ks) : -1;
     int total;

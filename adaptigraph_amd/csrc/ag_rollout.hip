@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
     const float *dl = a.delta + (size_t)b * a.N * 3;
     // shared-state rollout: a private prediction that differs from the base's in any bit makes the particle dirty from the next step on
     auto mark = [&](int n, int c, float v) {
-        if (cm && b > 0 && cm[n] != n && __float_as_uint(v) != __float_as_uint(pred[(size_t)n * 3 + c])) a.dirty[(size_t)b * a.N + n] = 1;
+        if (cm && b > 0 && cm[n] != n && __float_as_uint(v) != __float_as_uint(pred[(size_t)n * 3 + c])) { a.dirty[(size_t)b * a.N + n] = 1; a.sample_dirty[b] = 1; }
     };
     if (a.H == AG_NHIS) {
         // all of this thread's loads first, then its stores: `st` is read and written, so a plain loop orders every iteration's loads behind the

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void shared_stage_kernel(AgSharedArgs a)
     } else {
         a.s_mask[g] = mk ? 1 : 0;
         a.s_tool[g] = tl ? 1 : 0;
-        a.dirty[g] = (diff || tl || tl0 || mk != base_valid) ? 1 : 0;
+        const bool dn = diff || tl || tl0 || mk != base_valid;
+        a.dirty[g] = dn ? 1 : 0;
+        if (dn && !tl) a.sample_dirty[b1] = 1;      // (zeroed by the launcher)
     }
     if (i == 0) {
         for (int k = 0; k < a.phys_dim; ++k) a.s_phys[(size_t)b1 * a.phys_dim + k] = a.phys[(size_t)sb * a.phys_dim + k];
@@ -77,12 +79,51 @@ __global__ __launch_bounds__(256) void shared_stage_kernel(AgSharedArgs a)
     }
 }
 
+// Can this sample differ from the base at all in this step?  Only through a dirty particle, or through a tool that has a particle within the
+// interaction radius — the SAME arithmetic as the edge builder's pair test (separately rounded products, (d - thr) < 0): no pair in radius, no tool
+// edge, whatever top-k does.  One workgroup per sample; base: always.
+__global__ __launch_bounds__(256) void shared_active_kernel(AgSharedArgs a)
+{
+    constexpr int kTools = 32;
+    __shared__ float tx[kTools], ty[kTools], tz[kTools];
+    __shared__ int n_tools;
+    const int b = blockIdx.x, N = a.N;
+    if (b == 0) { if (threadIdx.x == 0) a.active[0] = 1; return; }
+    if (a.sample_dirty[b] != 0) { if (threadIdx.x == 0) a.active[b] = 1; return; }      // (uniform)
+    if (threadIdx.x == 0) n_tools = 0;
+    __syncthreads();
+    const float *pos = a.s_state + (((size_t)b * a.H + (a.H - 1)) * N) * 3;
+    const uint8_t *mk = a.s_mask + (size_t)b * N, *tl = a.s_tool + (size_t)b * N;
+    for (int i = threadIdx.x; i < N; i += 256)
+        if (tl[i] && mk[i]) {
+            const int k = atomicAdd(&n_tools, 1);
+            if (k < kTools) { tx[k] = pos[i * 3]; ty[k] = pos[i * 3 + 1]; tz[k] = pos[i * 3 + 2]; }
+        }
+    __syncthreads();
+    const int nt = n_tools;
+    bool any = nt > kTools;      // (more tools than the list holds: treat the sample as active)
+    const float thr = a.s_thr[b];
+    if (!any)
+        for (int i = threadIdx.x; i < N; i += 256) {
+            if (!mk[i] || tl[i]) continue;
+            const float x = pos[i * 3], y = pos[i * 3 + 1], z = pos[i * 3 + 2];
+            for (int k = 0; k < nt; ++k) {
+                const float dx = x - tx[k], dy = y - ty[k], dz = z - tz[k];
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                any = any || (d - thr) < 0.0f;
+            }
+        }
+    const int r = __syncthreads_or(any ? 1 : 0);
+    if (threadIdx.x == 0) a.active[b] = r ? 1 : 0;
+}
+
 // first-round set: dirty nodes, rows whose edge list is not the base's, rows with a dirty sender
 __global__ __launch_bounds__(256) void shared_touch_kernel(AgSharedArgs a)
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= (long long)a.B1 * a.N) return;
     const int b1 = (int)(g / a.N), i = (int)(g - (long long)b1 * a.N);
+    if (!a.active[b1]) { a.sel_a[g] = 0; return; }      // (its rows were not even built: they are the base's)
     bool sel = b1 == 0 || a.dirty[g] != 0;
     if (!sel) {
         const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1], f0 = a.row_ptr[i], f1 = a.row_ptr[i + 1];
@@ -101,6 +142,7 @@ __global__ __launch_bounds__(256) void shared_hop_kernel(AgSharedArgs a, const u
 {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= (long long)a.B1 * a.N) return;
+    if (!a.active[g / a.N]) { out[g] = 0; return; }
     bool sel = in[g] != 0;
     if (!sel) {
         const int e0 = a.row_ptr[g], e1 = a.row_ptr[g + 1];
@@ -191,7 +233,13 @@ __global__ __launch_bounds__(256) void shared_scatter_kernel(AgSharedArgs a)
 void ag_launch_shared_stage(const AgSharedArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.B1 * a.N;
+    (void)hipMemsetAsync(a.sample_dirty, 0, sizeof(int32_t) * a.B1, s);
     hipLaunchKernelGGL(shared_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void ag_launch_shared_active(const AgSharedArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(shared_active_kernel, dim3(a.B1), dim3(256), 0, s, a);
 }
 
 void ag_launch_shared_compact(const AgSharedArgs &a, hipStream_t s)

@@ -104,7 +104,10 @@ def _place_tool_lean(task, decoded, theta, y, device, zero=None):
     if n_t == 1:
         eef = torch.stack([decoded[:, 0], yy, decoded[:, 1]], dim=-1)[:, None]
     elif n_t == 5:
-        off = torch.tensor([0.0] + [float(pts[i][1]) * ratio for i in range(1, 5)], device=device)      # (key-point 0: x + 0 * sin is x + 0)
+        key = ("pusher_off", tuple(float(pts[i][1]) * ratio for i in range(1, 5)), str(device))      # (a host list -> device tensor is a synchronising copy: once per pusher)
+        off = _OFFSETS.get(key)
+        if off is None:
+            off = _OFFSETS[key] = torch.tensor([0.0] + list(key[1]), device=device)      # (key-point 0: x + 0 * sin is x + 0)
         sn, cs = torch.sin(theta), torch.cos(theta)
         ex = decoded[:, 0:1] + off[None] * sn[:, None]
         ez = decoded[:, 1:2] - off[None] * cs[:, None]
@@ -132,6 +135,7 @@ _CONST = collections.OrderedDict()      # per (batch, particles, tools, instance
 _CONST_MAX = 4                          # entries (an MPPI loop alternates between its chunk size and the bsz = 1 best-sample rollout: 2 live keys)
 _CONST_MAX_BYTES = 256 << 20            # and device bytes (20 000 samples x 200 particles: 66 MB per entry)
 _PINNED = {}
+_OFFSETS = {}                           # per (pusher geometry, device): key-point offsets of _place_tool_lean
 
 
 def _pinned(n, dtype, device):

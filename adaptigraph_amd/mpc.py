@@ -139,8 +139,14 @@ class MPPIPlanner:
     """Minimal planner with the reference Planner's MPPI branch (planner.py:38-326 keeps many unrelated modes)."""
 
     def __init__(self, model, device, ppm_optimizer, error_func, penalty_func, bbox, action_lower_lim, action_upper_lim,
-                 n_sample, n_look_ahead=1, n_update_iter=1, reward_weight=500.0, noise_level=1.0, rollout_best=True, n_sample_chunk=None):
+                 n_sample, n_look_ahead=1, n_update_iter=1, reward_weight=500.0, noise_level=1.0, rollout_best=True, n_sample_chunk=None,
+                 shared_state=True):
         task = ppm_optimizer.task_config
+        # Every rollout of this planner is ONE cloud under many sampled pushes (planner.py:246): let the engine roll the tool-less base trajectory out
+        # once and compute per sample only what can differ from it (ag_set_option "shared_state"; same bits, 8x fewer ms at 1 024 x 15 on rope-1k).
+        # None leaves the model's option as it is.
+        if shared_state is not None and hasattr(model, "set_option"):
+            model.set_option("shared_state", 1 if shared_state else 0)
         self.device = device
         self.lo = torch.as_tensor(action_lower_lim, dtype=torch.float32, device=device)
         self.hi = torch.as_tensor(action_upper_lim, dtype=torch.float32, device=device)
@@ -167,12 +173,17 @@ class MPPIPlanner:
 
     @torch.no_grad()
     def step(self, state_cur, act_seqs):
-        """One MPPI update from GIVEN samples: rollout, rewards, softmax-weighted new sequence."""
+        """One MPPI update from GIVEN samples: rollout, rewards, softmax-weighted new sequence.
+        The returned `out` may be a VIEW of the cached all-gather buffer (multi-GPU): valid until the next rollout of the same shape — clone what
+        has to outlive it."""
         if self.n_sample_chunk and self.n_sample_chunk < act_seqs.shape[0]:
             parts = [self.model_rollout(state_cur, a) for a in act_seqs.split(self.n_sample_chunk)]
             out = {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
         else:
-            out = self.model_rollout(state_cur, act_seqs, copy=False)
+            try:
+                out = self.model_rollout(state_cur, act_seqs, copy=False)
+            except TypeError:      # an externally assigned two-argument model_rollout (the reference's calling convention)
+                out = self.model_rollout(state_cur, act_seqs)
         reward = self.evaluate_traj(out["state_seqs"], act_seqs, state_cur=state_cur)["reward_seqs"]
         new_seq = optimize_action_mppi(act_seqs, reward, reward_weight=self.reward_weight, action_lower_lim=self.lo,
                                        action_upper_lim=self.hi, push_length=self.push_length)

@@ -64,7 +64,7 @@ def mppi_bench(dev, particles=1000, samples=1024, push_steps=15, steps=5, warmup
         error = partial(losses.chamfer, y=target_t[None])
     planner = mpc.MPPIPlanner(model, dev, ppm, error,
                               partial(losses.rope_penalty, sim_real_ratio=task["sim_real_ratio"]), bbox, lo, hi,
-                              n_sample=samples, n_update_iter=1, rollout_best=False, n_sample_chunk=chunk)
+                              n_sample=samples, n_update_iter=1, rollout_best=False, n_sample_chunk=chunk, shared_state=None if dry else bool(shared_state))
     if dry:
         from adaptigraph_amd.dist import dynamics_sharded
 

@@ -534,7 +534,14 @@ def test_shared_state_rollout_is_bitwise_the_plain_rollout(weights, mode, materi
 
     ref = run()
     m.set_option("shared_state", 1)
-    for _ in range(2):
+    for fill in (0xFF, 0x00, None):      # (whatever the scratch memory held: skipped samples leave their part of the graph arrays unwritten)
+        run()                            # sizes the workspace for the option
+        torch.cuda.synchronize()
+        for buf in aggraph._WS.values():
+            if fill is None:
+                buf.random_(0, 256)
+            else:
+                buf.fill_(fill)
         assert torch.isfinite(ref).all() and torch.equal(ref, run())
     for name, val, back in [("self_edges", 0, 1), ("node_stationary", 0, 1), ("node_dedup", 0, 1)] + ([("edge_stationary", 0, 1)] if mode == "fast" else []):
         m.set_option(name, val)
