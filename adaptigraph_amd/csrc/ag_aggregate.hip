@@ -102,8 +102,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 // adjacent lanes of one wave own a node, three nodes per wave, twelve per workgroup (240 of 256 lanes busy).
 constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 
+#ifndef AG_AGG_MINB
+#define AG_AGG_MINB 1      // A/B (tools/ab_build.sh): minimum workgroups per CU = waves per SIMD the register allocation must allow
+#endif
 template <bool HSQ, bool SELF, bool DEV>
-__global__ __launch_bounds__(256) void aggregate_half_kernel(AgFwdArgs a)
+__global__ __launch_bounds__(256, AG_AGG_MINB) void aggregate_half_kernel(AgFwdArgs a)
 {
     ag_overflow_view(a);
     const int rows = (DEV && a.n_rows_dev) ? *a.n_rows_dev : a.B * a.N;

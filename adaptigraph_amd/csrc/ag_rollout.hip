@@ -15,14 +15,16 @@ namespace {
 
 constexpr int kStepChunk = 2048;     // plane elements per workgroup
 
+// SHARED (compile time: the plain rollout keeps its direct indexing — the map costs it 25 % of this launch): the shared-state rollout of ag_shared.hip
+template <bool SHARED>
 __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 {
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // prediction of particle i, component c: by (sample, particle), or — shared-state rollout — by compact row through cmap (a private row or the base's)
-    const float *pred = a.pred_pos + (a.cmap ? (size_t)0 : (size_t)b * a.n_p * 3);
-    const int32_t *cm = a.cmap ? a.cmap + (size_t)b * a.N : nullptr;
-    auto at = [&](int i, int c) { return pred[(size_t)(cm ? cm[i] : i) * 3 + c]; };
+    const float *pred = a.pred_pos + (SHARED ? (size_t)0 : (size_t)b * a.n_p * 3);
+    const int32_t *cm = SHARED ? a.cmap + (size_t)b * a.N : nullptr;
+    auto at = [&](int i, int c) { return SHARED ? pred[(size_t)cm[i] * 3 + c] : pred[i * 3 + c]; };
 
     float y;
     if (a.height_mode == 0) {
@@ -51,15 +53,16 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 
     const int plane = a.N * 3;
     const int k0 = blockIdx.y * kStepChunk, k1 = min(k0 + kStepChunk, plane);
-    if (a.repeat[b] == a.step && !(cm && b == 0)) {
-        float *o = a.out_seq + (size_t)(cm ? b - 1 : b) * a.n_p * 3;      // (shared-state rollout: internal sample b is the caller's b - 1; the base records nothing)
-        for (int k = k0 + tid; k < min(k1, a.n_p * 3); k += 256) o[k] = at(k / 3, k % 3);
+    if (a.repeat[b] == a.step && !(SHARED && b == 0)) {
+        float *o = a.out_seq + (size_t)(SHARED ? b - 1 : b) * a.n_p * 3;      // (shared-state rollout: internal sample b is the caller's b - 1; the base records nothing)
+        for (int k = k0 + tid; k < min(k1, a.n_p * 3); k += 256) o[k] = SHARED ? at(k / 3, k % 3) : pred[k];
     }
     float *st = a.state + (size_t)b * a.H * a.N * 3;
     const float *dl = a.delta + (size_t)b * a.N * 3;
     // shared-state rollout: a private prediction that differs from the base's in any bit makes the particle dirty from the next step on
     auto mark = [&](int n, int c, float v) {
-        if (cm && b > 0 && cm[n] != n && __float_as_uint(v) != __float_as_uint(pred[(size_t)n * 3 + c])) { a.dirty[(size_t)b * a.N + n] = 1; a.sample_dirty[b] = 1; }
+        if constexpr (SHARED)
+            if (b > 0 && cm[n] != n && __float_as_uint(v) != __float_as_uint(pred[(size_t)n * 3 + c])) { a.dirty[(size_t)b * a.N + n] = 1; a.sample_dirty[b] = 1; }
     };
     if (a.H == AG_NHIS) {
         // all of this thread's loads first, then its stores: `st` is read and written, so a plain loop orders every iteration's loads behind the
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 #pragma unroll
                 for (int h = 1; h < AG_NHIS; ++h) v[i][h] = st[(size_t)h * plane + k];
                 const int n = k / 3, c = k - n * 3;
-                nv[i] = n < a.n_p ? at(n, c) : (c == 1 ? y : v[i][AG_NHIS - 1] + dl[k]);
+                nv[i] = n < a.n_p ? (SHARED ? at(n, c) : pred[k]) : (c == 1 ? y : v[i][AG_NHIS - 1] + dl[k]);
                 if (n < a.n_p) mark(n, c, nv[i]);
             }
         }
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
         const float last = st[(size_t)(a.H - 1) * plane + k];
         for (int h = 0; h + 1 < a.H; ++h) st[(size_t)h * plane + k] = st[(size_t)(h + 1) * plane + k];
         float nv;
-        if (n < a.n_p) { nv = at(n, c); mark(n, c, nv); }
+        if (n < a.n_p) { nv = SHARED ? at(n, c) : pred[k]; mark(n, c, nv); }
         else nv = (c == 1) ? y : last + dl[k];
         st[(size_t)(a.H - 1) * plane + k] = nv;
     }
@@ -103,5 +106,7 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(rollout_step_kernel, dim3(a.B, (a.N * 3 + kStepChunk - 1) / kStepChunk), dim3(256), 0, s, a);
+    const dim3 grid(a.B, (a.N * 3 + kStepChunk - 1) / kStepChunk);
+    if (a.cmap) hipLaunchKernelGGL(rollout_step_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rollout_step_kernel<false>, grid, dim3(256), 0, s, a);
 }
