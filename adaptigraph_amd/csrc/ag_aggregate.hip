@@ -102,8 +102,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AgFwdArgs a)
 // adjacent lanes of one wave own a node, three nodes per wave, twelve per workgroup (240 of 256 lanes busy).
 constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 
+// Minimum workgroups per CU = waves per SIMD the register allocation must allow.  Left alone hipcc takes 94-110 registers (4 waves per SIMD); at 5
+// (<= 96 registers) the reduce is 2-3 % shorter on all three workloads (0.2095 -> 0.2048 ms rope C2, 0.407 -> 0.399 granular, 0.158 -> 0.153 cloth); 6
+// spills (0.349), 8 is hopeless (0.835); fewer or more edges in flight per lane (2, 3, 5, 6) change nothing or lose (profiles/r06_agg_occupancy_ab.txt).
 #ifndef AG_AGG_MINB
-#define AG_AGG_MINB 1      // A/B (tools/ab_build.sh): minimum workgroups per CU = waves per SIMD the register allocation must allow
+#define AG_AGG_MINB 5
 #endif
 template <bool HSQ, bool SELF, bool DEV>
 __global__ __launch_bounds__(256, AG_AGG_MINB) void aggregate_half_kernel(AgFwdArgs a)
