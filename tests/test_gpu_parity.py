@@ -585,6 +585,63 @@ def test_shared_state_rollout_with_distinct_states_degrades_to_the_plain_rollout
     assert m.take_status() == 0
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_shared_state_rollout_random_cases(weights, seed):
+    """Randomised plain-vs-shared comparison through the raw rollout: material, 1 ... 700 particles (both edge-builder paths), 2 ... 40 samples, 1 ... 4 model
+    steps, per-sample step counts, tools near / far / absent-minded (some samples park theirs far away), invalid object slots — shared by all samples or per
+    sample —, padded slots, a few samples with a perturbed cloud, another physics parameter or radius, the masked-mean tool height, every arithmetic mode.
+    Final states and recorded predictions equal bit for bit, status 0."""
+    rng = np.random.default_rng(1000 + seed)
+    material = ("rope", "granular", "cloth")[seed % 3]
+    mm = synth.MATERIALS[material]
+    n_obj = int(rng.choice([1, 7, 40, 150, 300, 700])) if material != "cloth" else int(rng.choice([16, 144, 625]))
+    B, steps = int(rng.integers(2, 41)), int(rng.integers(1, 5))
+    mode = ("fast", "bf16x3", "f32")[(seed // 3) % 3]
+    m = make_model(weights, material, prec=mode)
+    g = synth.make_graph_inputs(material, n_obj, B, seed=seed, n_pad=int(rng.integers(0, 3)), **(dict(spacing=0.1) if material == "rope" else {}))
+    n_p, N, n_t = g["n_p"], g["attrs"].shape[1], g["n_tools"]
+    g["state"][:] = g["state"][:1]                                           # one cloud ...
+    far = rng.uniform(size=B) < 0.4                                          # ... every sample its own tool pose, some far away
+    g["state"][:, :, n_p:] += rng.normal(0, 0.4, (B, 1, 1, 3)).astype(np.float32) + far[:, None, None, None] * np.float32(30.0)
+    g["action"][:, n_p:] = rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32)
+    if rng.uniform() < 0.5:
+        g["mask"][:, :n_obj] &= rng.uniform(size=(1, n_obj)) < 0.9           # invalid slots shared by all samples
+    if rng.uniform() < 0.4:
+        g["mask"][:, :n_obj] &= rng.uniform(size=(B, n_obj)) < 0.97          # ... and per sample (those nodes differ from the base)
+    for b in rng.choice(B, size=max(1, B // 6), replace=False):              # a few samples that share less
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            g["state"][b, :, :n_obj] += rng.normal(0, 0.004, (4, n_obj, 3)).astype(np.float32)
+        elif kind == 1:
+            g["phys"][b] = 0.9
+        else:
+            g["state"][b, -1, int(rng.integers(0, n_obj))] += 0.03
+    radius = np.full(B, mm["radius"], np.float32)
+    if rng.uniform() < 0.3:
+        radius[int(rng.integers(0, B))] *= 1.1
+    thr = aggraph.threshold_sq(t(radius), B, torch.device(DEV), _lib.AG_VARIANT_BATCH)
+    rep = t(rng.integers(1, steps + 1, B).astype(np.int32))
+    masked = bool(rng.uniform() < 0.3)
+    obj_mask = t(g["mask"][:, :n_p]) if masked else None
+    if masked and not g["mask"][:, :n_p].any(1).all():
+        masked, obj_mask = False, None
+
+    def run():
+        return tuple(x.clone() for x in rollout(m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]),
+                                                thr, rep, steps, mm["topk"], mm["connect_tools_all"], n_t,
+                                                _lib.AG_HEIGHT_MASKED_MEAN if masked else _lib.AG_HEIGHT_MIN, obj_mask, 0.0, return_state=True))
+
+    ref = run()
+    m.set_option("shared_state", 1)
+    run()
+    torch.cuda.synchronize()
+    for buf in aggraph._WS.values():
+        buf.random_(0, 256)
+    got = run()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)), (material, n_obj, B, steps, mode)
+    m.take_status()
+
+
 def test_shared_state_rollout_at_the_mpc_shape_computes_a_fraction_of_the_edges(weights):
     """BASELINE configs[4] on one GPU (rope-1000 + tool, 1 024 sampled pushes x 15 model steps): bit-equal to the plain rollout, and the edge encoder
     walks a small fraction of the plain rollout's edges (the library's per-launch edge counter): most samples' tools never touch the rope."""
