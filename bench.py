@@ -565,7 +565,7 @@ def main():
                        "model_status": r["model_status"],
                        # engine options the timed region ran with (ag_get_option): self-loops as one table row per attribute class (exact, r06);
                        # shared_state 0 = every sample computed in full (the option's numbers are the separate shared_state_* / mpc_ms keys)
-                       "self_edges": None if args.dry_run else eng.get("self_edges"), "shared_state": None if args.dry_run else eng.get("shared_state")},
+                       "self_edges": -1 if args.dry_run else eng.get("self_edges"), "shared_state": -1 if args.dry_run else eng.get("shared_state")},
             "arithmetic": DTYPE[args.precision],
             "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }
