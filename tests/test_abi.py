@@ -58,6 +58,8 @@ def test_errors_are_codes_not_crashes():
     h = ctypes.c_void_p()
     assert L.ag_model_create(None, None, ctypes.byref(h)) != 0
     assert b"null" in L.ag_last_error()
+    v = ctypes.c_int(7)
+    assert L.ag_get_option(None, b"precision", ctypes.byref(v)) != 0 and b"null" in L.ag_last_error() and v.value == 7
     bad = _lib.ModelConfig(128, 4, 2, 1, 3, 3, 100.0)              # nf the kernels are not built for
     dummy = (ctypes.c_void_p * 22)(*([1] * 22))
     assert L.ag_model_create(ctypes.byref(bad), dummy, ctypes.byref(h)) == -4

@@ -1026,6 +1026,26 @@ def test_cu_partitioned_rollout_is_bitwise_the_shared_chip_rollout(weights, spli
         m.set_option("cu_split", 100)           # not a multiple of 8
 
 
+def test_get_option_reports_what_the_engine_runs_with(weights):
+    """ag_get_option: the model's current value of every option of ag_set_option (defaults, then what was set); unknown names are an error code."""
+    import ctypes
+    m = make_model(weights, "rope", prec="fast")
+    L, h = _lib.lib(), m.handle(torch.device(DEV))
+
+    def get(name):
+        v = ctypes.c_int(-99)
+        _lib.check(L.ag_get_option(h, name.encode(), ctypes.byref(v)), name)
+        return v.value
+
+    assert (get("precision"), get("self_edges"), get("shared_state"), get("node_dedup"), get("rollout_streams"), get("fuse_aggregate")) == (2, 1, 0, 1, 0, 0)
+    for name, val in (("precision", 1), ("precision", 0), ("self_edges", 0), ("shared_state", 1), ("node_dedup", 2), ("rollout_streams", 3), ("edge_products", 3),
+                      ("edge_stationary", 0), ("node_stationary", 0), ("cu_split", 64), ("fuse_aggregate", 2)):
+        m.set_option(name, val)
+        assert get(name) == val, name
+    v = ctypes.c_int()
+    assert L.ag_get_option(h, b"no_such_option", ctypes.byref(v)) != 0 and b"unknown option" in L.ag_last_error()
+
+
 def test_rollout_stream_count_default_follows_the_workload_and_never_changes_a_bit(weights):
     """"rollout_streams" 0 (the default): one stream, two where the edge stack dominates the step (top-k >= 16: granular), never more than B / 8
     parts; 1..4 are taken as given (ag_rollout_streams_for reports what ag_rollout will do).  Graphs never interact: every count gives the same bits."""
