@@ -459,7 +459,7 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
 // tables no later kernel overwrites — ag_rollout runs this ONCE per call instead of once per model step.
 void run_node_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
-    if (a.dedup) (void)hipMemsetAsync(a.enc_count, 0, 3 * sizeof(int), s);      // enc_count, priv_count, ovf
+    if (a.dedup) ag_launch_zero_words(a.enc_count, 3, s);      // enc_count, priv_count, ovf (a kernel: memset nodes of a captured graph were not replayed reliably)
     { Timed t(m, AG_K_NODE_ENCODE, s); ag_launch_node_encode(m->w, a, s); }
 }
 
@@ -480,7 +480,7 @@ void run_edge_encode(ag_model *m, AgFwdArgs &a, hipStream_t s)
 {
     // row-tile claim counter of the STREAMING edge encoders; the weight-stationary kernel (default mode) deals its blocks statically: no fill launch
     const bool ws = edge_ws_path(a);
-    if (a.tile_ctr && !ws) (void)hipMemsetAsync(a.tile_ctr, 0, sizeof(int), s);
+    if (a.tile_ctr && !ws) ag_launch_zero_words(a.tile_ctr, 1, s);
     { Timed t(m, AG_K_EDGE_ENCODE, s); ag_launch_edge_encode(m->w, a, s); if (a.dedup && !ws && !a.remap_done) ag_launch_send_remap(a, s); }      // (ws: mapped by the node-table launch)
 }
 

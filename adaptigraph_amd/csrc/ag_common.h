@@ -413,6 +413,7 @@ struct AgStepArgs {
     float raise;              // gripper raise (0 when disabled)
 };
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s);
+void ag_launch_zero_words(int32_t *p, int n, hipStream_t s);      // (a kernel, not a memset node: HIP-graph replay)
 
 // ---- shared-state rollout (ag_shared.hip) ------------------------------------------------------------------------------------
 // dynamics() rolls ONE cloud out under `bsz` sampled pushes (forward_dynamics.py:11-38; 20 000 samples per planning step in config/planning/rope.yaml):

@@ -882,7 +882,7 @@ int ag_launch_build_edges(const AgEdgeArgs &a, hipStream_t s)
     // (connect_tools_all: the per-sample batch_mask word is cleared by bin_kernel on the cell path — one fill launch per step less)
     static const int force = getenv("AG_EDGE_CELLS") ? atoi(getenv("AG_EDGE_CELLS")) : -1;   // -1 auto, 0 brute force, 1 cells
     const bool cells = force < 0 ? a.N >= 256 : force != 0;
-    if (a.connect && !cells) (void)hipMemsetAsync(a.flag, 0, sizeof(int32_t) * a.B, s);
+    if (a.connect && !cells) ag_launch_zero_words(a.flag, a.B, s);
     if (cells) {
         const int nb_tab = a.tab_out ? (rows + 255) / 256 : 0;        // rider workgroups follow the B binning ones
         hipLaunchKernelGGL(bin_kernel, dim3(a.B + nb_tab), dim3(256), 0, s, a);

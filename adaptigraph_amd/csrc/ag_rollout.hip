@@ -104,6 +104,18 @@ __global__ __launch_bounds__(256) void rollout_step_kernel(AgStepArgs a)
 
 }  // namespace
 
+// Zero a few device words with a KERNEL instead of hipMemsetAsync: inside a captured HIP graph the memset NODES of the shared-state rollout were not
+// reliably replayed (second replay of tests' graph: garbage; eager calls and the first replay fine), kernel nodes are.
+__global__ void zero_words_kernel(int32_t *p, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+void ag_launch_zero_words(int32_t *p, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(zero_words_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+
 void ag_launch_rollout_step(const AgStepArgs &a, hipStream_t s)
 {
     const dim3 grid(a.B, (a.N * 3 + kStepChunk - 1) / kStepChunk);

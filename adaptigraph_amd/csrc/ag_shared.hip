@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void shared_scatter_kernel(AgSharedArgs a)
 void ag_launch_shared_stage(const AgSharedArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.B1 * a.N;
-    (void)hipMemsetAsync(a.sample_dirty, 0, sizeof(int32_t) * a.B1, s);
+    ag_launch_zero_words(a.sample_dirty, a.B1, s);
     hipLaunchKernelGGL(shared_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 

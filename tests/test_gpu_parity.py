@@ -1083,6 +1083,10 @@ def test_rollout_is_hip_graph_capturable(weights):
     rep = torch.tensor([(b % T) + 1 for b in range(B)], dtype=torch.int32, device=dev)
     args = (m, t(g["state"]), t(g["action"]), t(g["attrs"]), t(g["p_instance"]), t(g["phys"]), t(g["mask"]), t(g["tool_mask"]), thr, rep, T, 10, False, 1)
     ref = ag_roll(*args).clone()
+    if os.environ.get("AG_SHARED_STATE") == "1":      # (suite-wide run of the shared-state rollout: the eager result must be the plain path's)
+        m.set_option("shared_state", 0)
+        assert torch.equal(ref, ag_roll(*args)), "eager shared-state rollout differs from the plain one"
+        m.set_option("shared_state", 1)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -1091,11 +1095,27 @@ def test_rollout_is_hip_graph_capturable(weights):
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
         out = ag_roll(*args)
-    for _ in range(2):
+    for _ in range(3):
         out.zero_()
         gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+    # ... and with what a planner would switch on: the shared-state rollout and a forced node de-duplication (device words zeroed per call — by a
+    # kernel: r06 found hipMemsetAsync NODES of a captured graph not replayed reliably, the second replay ran with the first one's counters)
+    for name, val in (("node_dedup", 2), ("shared_state", 1)):
+        m.set_option(name, val)
+        with torch.cuda.stream(side):
+            assert torch.equal(ag_roll(*args), ref)
+        torch.cuda.current_stream().wait_stream(side)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            out2 = ag_roll(*args)
+        for _ in range(3):
+            out2.zero_()
+            g2.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out2, ref), name
+    assert m.take_status() == 0
 
 
 @pytest.mark.parametrize("name", golden_files("dynmask_"))
