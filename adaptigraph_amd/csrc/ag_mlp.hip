@@ -2273,7 +2273,7 @@ void ag_launch_train_pack(const float *W, const float *bias, int n_out, int n_in
                           int n_tiles, int b3, float *dst, hipStream_t s)
 {
     if (b3) {
-        if (compact) (void)hipMemsetAsync(dst, 0, AG_CHUNK_FLOATS * sizeof(float), s);      // the compact image has unused tail bytes when NU = 1
+        if (compact) ag_launch_zero_words(reinterpret_cast<int32_t *>(dst), AG_CHUNK_FLOATS, s);      // the compact image has unused tail bytes when NU = 1
         const int total = (compact ? AG_NT * ((n_in + 1 + 15) / 16) : n_tiles * 10) * 512;
         hipLaunchKernelGGL(train_pack_b3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, W, bias, n_out, n_in, ld, col0, transposed, compact, n_tiles, dst);
         return;
