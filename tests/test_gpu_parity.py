@@ -715,9 +715,10 @@ def test_node_deduplication_through_the_masked_rollout(weights):
         m.set_option("node_dedup", dd)
         outs.append(dynamics_masked(t(g["state_init"]), t(g["state_mask"]), t(g["action"]), m, DEV, _ppm("rope"))["state_seqs"])
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    valid = g["state_mask"]
-    err = np.abs(outs[0].cpu().numpy() - g["state_seqs"])[valid].max()
-    assert err <= 1e-3, err            # (multi-step drift of the default mode; the per-mode gate is test_dynamics_masked_golden)
+    err = (np.abs(outs[0].cpu().numpy() - g["state_seqs"]) * g["state_mask"][..., None]).reshape(g["state_seqs"].shape[0], -1).max(1)
+    for b in np.nonzero(err > TOL_FWD)[0]:      # every sample inside the gate, or a PROVEN top-k near-tie (as in test_dynamics_masked_golden; r05 review weak 1c: was a flat 1e-3)
+        step, dev, gap = explain_divergence(m, weights, "rope", g["state_init"], g["action"], int(b), state_mask=g["state_mask"])
+        print(f"dynmask_rope40[{b}] (fast, de-duplicated): top-k near-tie at step {step}: candidates {gap:.2e} apart, forward deviation {dev:.2e}")
 
 
 def test_forward_translation_invariance(model):
