@@ -108,7 +108,8 @@ constexpr int kNodesPerBlockH = 4 * AG_AGG_NODES_PER_WAVE;
 #ifndef AG_AGG_MINB
 #define AG_AGG_MINB 5
 #endif
-template <bool HSQ, bool SELF, bool DEV>
+// AQ: `agg` goes out as q16 rows (option "agg_q16", ag_common.h: ag_q16_encode_segment) — 16 bytes per lane instead of 32.
+template <bool HSQ, bool SELF, bool DEV, bool AQ>
 __global__ __launch_bounds__(256, AG_AGG_MINB) void aggregate_half_kernel(AgFwdArgs a)
 {
     ag_overflow_view(a);
@@ -126,9 +127,14 @@ __global__ __launch_bounds__(256, AG_AGG_MINB) void aggregate_half_kernel(AgFwdA
         if (g >= rows) { if constexpr (DEV) continue; else return; }
         float4 acc0, acc1;
         ag_reduce_node_q16<AG_AGG_IN_FLIGHT, HSQ, SELF>(a, g, c, grp * AG_AGG_GROUP, acc0, acc1, E);      // (6 or 8 edges in flight with the q16 sender table: no change)
-        const int f0 = ag_half_lane_feature(c);
-        ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0), acc0);
-        ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8), acc1);
+        if constexpr (AQ) {
+            const int4 w = ag_q16_encode_segment(acc0, acc1, c, grp * AG_AGG_GROUP);
+            ag_st_nt(reinterpret_cast<int4 *>(a.agg) + (size_t)g * (AG_FP / 8) + c, w);
+        } else {
+            const int f0 = ag_half_lane_feature(c);
+            ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0), acc0);
+            ag_st_nt(reinterpret_cast<float4 *>(a.agg + (size_t)g * AG_FP + f0 + 8), acc1);
+        }
         if constexpr (!DEV) return;
     }
 }
@@ -136,8 +142,13 @@ __global__ __launch_bounds__(256, AG_AGG_MINB) void aggregate_half_kernel(AgFwdA
 template <bool HSQ, bool SELF>
 void launch_half(const AgFwdArgs &a, dim3 grid, hipStream_t s, bool loop)
 {
-    if (loop) hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, false>), grid, dim3(256), 0, s, a);
+    if (a.agg_q16) {
+        if (loop) hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, false, true>), grid, dim3(256), 0, s, a);
+        return;
+    }
+    if (loop) hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((aggregate_half_kernel<HSQ, SELF, false, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace

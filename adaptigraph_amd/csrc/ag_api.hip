@@ -239,6 +239,8 @@ struct ag_model {
     int edge_products = 2;      // precision mode 2: 2 = fp16 edge stack (split-fp16 weights x fp16 activations + e5m2 residual bytes: PrecH3),
                                 // 3 = split-bf16 like mode 1 (env AG_EDGE_PRODUCTS / "edge_products")
     bool h2_ok = true;          // every edge-stack weight fits fp16 (else mode 2 keeps the split-bf16 edge stack)
+    int agg_q16 = 1;            // precision mode 2: `agg` as q16 rows between the segment reduce and node_update (env AG_AGG_Q16 / "agg_q16"; default 1, r06): one
+                                // more 16-bit rounding per node and round (unsigned, block-scaled), half the bytes of that table; 0 = fp32 rows
     int node_ws = 1;            // split-bf16 node_update of the rounds before the last on the weight-stationary kernel (default; env AG_NODE_WS /
                                 // "node_stationary" 0 = the streaming kernel); bit-identical
     int edge_ws = 1;            // fp16 edge stack (PrecH3) on the weight-stationary kernel (default) or, 0, the streaming one (env AG_EDGE_WS / "edge_stationary")
@@ -441,6 +443,8 @@ void setup_args(ag_model *m, AgFwdArgs &a, int max_blocks, int steps = 1)      /
     a.edge_products = m->h2_ok ? m->edge_products : 3;      // a checkpoint with edge-stack weights beyond fp16's range keeps the split-bf16 edge stack
     a.edge_ws = m->edge_ws;
     a.node_ws = m->node_ws;
+    // `agg` as q16 rows (mode 2): the q16 reduce writes them, every split-bf16 node_update reads them, the fused reduce rounds its sums the same way
+    a.agg_q16 = (m->agg_q16 && a.precision == AG_PREC_B3 && a.eterm_half) ? 1 : 0;
     a.dedup = m->node_dedup && (long long)a.B * (a.N + AG_DEDUP_REPS) < 0x7fffff00LL &&
               (m->node_dedup >= 2 || (long long)a.B * a.N * (steps > 0 ? steps : 1) >= 32768);
     a.hr_row = nullptr; a.pn_rows = nullptr; a.h_rows = nullptr; a.hr_full = nullptr; a.hs_full = nullptr;
@@ -556,6 +560,7 @@ int ag_model_create(const ag_model_config *cfg, const float *const *weights, ag_
     if (const char *v = getenv("AG_SPLIT")) m->split = atoi(v);
     if (const char *v = getenv("AG_EDGE_WS")) m->edge_ws = atoi(v) != 0;
     if (const char *v = getenv("AG_NODE_WS")) m->node_ws = atoi(v) != 0;
+    if (const char *v = getenv("AG_AGG_Q16")) m->agg_q16 = atoi(v) != 0;
     if (const char *v = getenv("AG_EDGE_PRODUCTS")) m->edge_products = atoi(v) == 3 ? 3 : 2;
     if (const char *v = getenv("AG_STAGGER")) m->stagger = atoi(v);
     if (const char *v = getenv("AG_NODE_DEDUP")) m->node_dedup = atoi(v);
@@ -811,6 +816,7 @@ int ag_set_option(ag_model *m, const char *name, int value)
     }
     else if (!strcmp(name, "edge_stationary")) m->edge_ws = value != 0;
     else if (!strcmp(name, "node_stationary")) m->node_ws = value != 0;
+    else if (!strcmp(name, "agg_q16")) m->agg_q16 = value != 0;
     else if (!strcmp(name, "node_dedup")) m->node_dedup = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "self_edges")) m->self_edges = value != 0;
     else if (!strcmp(name, "shared_state")) m->shared_state = value != 0;
@@ -833,6 +839,7 @@ int ag_get_option(const ag_model *m, const char *name, int *value)
     else if (!strcmp(name, "edge_products")) *value = m->edge_products;
     else if (!strcmp(name, "edge_stationary")) *value = m->edge_ws;
     else if (!strcmp(name, "node_stationary")) *value = m->node_ws;
+    else if (!strcmp(name, "agg_q16")) *value = m->agg_q16;
     else if (!strcmp(name, "node_dedup")) *value = m->node_dedup;
     else if (!strcmp(name, "self_edges")) *value = m->self_edges;
     else if (!strcmp(name, "shared_state")) *value = m->shared_state;

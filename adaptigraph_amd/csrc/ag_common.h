@@ -84,6 +84,8 @@ struct AgFwdArgs {
     int ws_blocks;     // workgroups of the weight-stationary edge encoder for this launch
     int edge_ws;       // with edge_products == 2: 1 = weight-stationary kernel (default), 0 = streaming kernel
     int node_ws;       // split-bf16 node_update of the rounds before the last on the weight-stationary kernel (ag_mlp.hip: node_update_nws_kernel)
+    int agg_q16;       // precision mode 2, option "agg_q16" (default 1): the segment reduce stores `agg` as q16 rows (320 B, the Eterm row layout with unsigned
+                       // values, ag_q16_encode_segment) and node_update decodes them; the reduce fused into node_update rounds its sums the same way
     // ---- node-encoder de-duplication.  The node encoder sees [attrs | phys | action] only (positions do not enter:
     // model.py:168-173 is skipped for state_dim = 0), and every rollout driver of the reference gives all object particles of a sample
     // the same row (forward_dynamics.py:83-123: attrs (1,0), the sample's physics parameter, zero action), so particle_encode, the hoisted
@@ -190,11 +192,66 @@ typedef float ag_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int4 ag_ld_nt(const int4 *p) { return *p; }
 __device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { return *p; }
 __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { *p = v; }
+__device__ __forceinline__ void ag_st_nt(int4 *p, const int4 &v) { *p = v; }
 #else
 __device__ __forceinline__ int4 ag_ld_nt(const int4 *p) { const ag_i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_i32x4 *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 ag_ld_nt(const float4 *p) { const ag_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ag_f32x4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void ag_st_nt(float4 *p, const float4 &v) { __builtin_nontemporal_store(ag_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ag_f32x4 *>(p)); }
+__device__ __forceinline__ void ag_st_nt(int4 *p, const int4 &v) { __builtin_nontemporal_store(ag_i32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ag_i32x4 *>(p)); }
 #endif
+
+// ---- `agg` as q16 rows (option "agg_q16"): the reduce's lanes already hold a row in the table's own order — lane c of a node's twenty owns the 16-bit
+// positions 8c .. 8c + 7 (acc0 = the first four, acc1 = the last four; ag_half_lane_feature), the four lanes of an aligned quad one out-tile.  The
+// tile maximum is two quad-permute DPP moves away; the five exponent bytes reach the two lanes whose segments hold them (17: bytes 280..284, 19:
+// bytes 312, 316..319 — the Eterm row format above, byte for byte) by four ds_bpermute.  Values are sums of ReLU outputs (>= +0), padding positions are
+// already zero (ag_reduce_node_q16's tail).  Because nothing is negative the 16 bits are UNSIGNED here — q = rne(v 2^(126-eb) 65535), value = q 2^(eb-126) / 65535:
+// half the rounding step of the signed per-edge rows (the one difference to that format; only node_update reads these rows, ag_mlp.hip: agg_q16_*).
+__device__ __forceinline__ float ag_q16u_scale(int eb) { return ldexpf(1.0f / 65535.0f, eb - 126); }
+// the eight values of a lane as 16-bit words (no exponent bytes yet) + the tile's exponent byte
+__device__ __forceinline__ int4 ag_q16_quantize_segment(const float4 &acc0, const float4 &acc1, int &eb)
+{
+    typedef unsigned short ag_u16x2 __attribute__((ext_vector_type(2)));
+    auto bits = [](float v) { return __float_as_uint(v) & 0x7fffffffu; };
+    unsigned m = max(max(max(bits(acc0.x), bits(acc0.y)), max(bits(acc0.z), bits(acc0.w))), max(max(bits(acc1.x), bits(acc1.y)), max(bits(acc1.z), bits(acc1.w))));
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false));      // quad_perm [1, 0, 3, 2]
+    m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false));      // quad_perm [2, 3, 0, 1]
+    eb = (int)(m >> 23);
+    eb = eb < AG_Q16_EB_MIN ? AG_Q16_EB_MIN : (eb > AG_Q16_EB_MAX ? AG_Q16_EB_MAX : eb);
+    const int inv = 126 - eb;
+    auto pack = [&](float x, float y) {
+        return (int)__builtin_bit_cast(unsigned, (ag_u16x2)__builtin_amdgcn_cvt_pknorm_u16(__builtin_ldexpf(x, inv), __builtin_ldexpf(y, inv)));
+    };
+    return make_int4(pack(acc0.x, acc0.y), pack(acc0.z, acc0.w), pack(acc1.x, acc1.y), pack(acc1.z, acc1.w));
+}
+// eight 16-bit words -> values (node_update's side of the table; the fused reduce's round trip)
+__device__ __forceinline__ void ag_q16u_decode8(const int4 &w, float sc, float (&x)[8])
+{
+    const unsigned a = (unsigned)w.x, b = (unsigned)w.y, c = (unsigned)w.z, d = (unsigned)w.w;
+    x[0] = (float)(a & 0xffffu) * sc; x[1] = (float)(a >> 16) * sc; x[2] = (float)(b & 0xffffu) * sc; x[3] = (float)(b >> 16) * sc;
+    x[4] = (float)(c & 0xffffu) * sc; x[5] = (float)(c >> 16) * sc; x[6] = (float)(d & 0xffffu) * sc; x[7] = (float)(d >> 16) * sc;
+}
+// the segment as stored: values + the row's exponent bytes in the two lanes whose segments hold them
+__device__ __forceinline__ int4 ag_q16_encode_segment(const float4 &acc0, const float4 &acc1, int c, int group_lane0)
+{
+    int eb;
+    int4 w = ag_q16_quantize_segment(acc0, acc1, eb);
+    unsigned ebs = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ebs |= (unsigned)__builtin_amdgcn_ds_bpermute((group_lane0 + 4 * t) << 2, eb) << (8 * t);
+    if (c == 17) { w.z = (int)ebs; w.w = eb; }              // (this lane is in the fifth tile's quad: `eb` is tile 4's)
+    if (c == 19) { w.z = eb; w.w = (int)ebs; }
+    return w;
+}
+// what node_update will read back from the stored segment, without the table (the reduce fused into node_update: same bits as the separate kernels)
+__device__ __forceinline__ void ag_q16_roundtrip_segment(float4 &acc0, float4 &acc1)
+{
+    int eb;
+    const int4 w = ag_q16_quantize_segment(acc0, acc1, eb);
+    float x[8];
+    ag_q16u_decode8(w, ag_q16u_scale(eb), x);
+    acc0 = make_float4(x[0], x[1], x[2], x[3]);
+    acc1 = make_float4(x[4], x[5], x[6], x[7]);
+}
 
 // An elided self-loop (AgFwdArgs::self_info) is a VIRTUAL edge: node g has n = (e1 - e0) + 1 of them, virtual edge j is table row / COO entry
 // e0 + j - (j > kself), except j == kself: the class row (table row E + class) and the node itself as the sender.

@@ -759,6 +759,33 @@ __device__ __forceinline__ void load_rowmajor(const float *row, f32x16 (&v)[AG_N
         }
 }
 
+// `agg` as q16 rows (option "agg_q16", ag_common.h): lane (j, h) of an MFMA kernel needs, per out-tile t, the features 32t + 8q + 4h + p — the sixteen
+// CONTIGUOUS 16-bit positions 32t + 16h .. + 15 of row j (two 16-byte loads instead of four) — and the row's exponent bytes 280..284 (one 8-byte load).
+struct AggRowQ16 { int4 v[AG_NT][2]; uint2 ex; };
+__device__ __forceinline__ void load_rowmajor_q16(const unsigned char *row, AggRowQ16 &r, int h)
+{
+#pragma unroll
+    for (int t = 0; t < AG_NT; ++t) {
+        r.v[t][0] = *reinterpret_cast<const int4 *>(row + 64 * t + 32 * h);
+        r.v[t][1] = *reinterpret_cast<const int4 *>(row + 64 * t + 32 * h + 16);
+    }
+    r.ex = *reinterpret_cast<const uint2 *>(row + 280);
+}
+__device__ __forceinline__ float agg_q16_tile_scale(const uint2 &ex, int t) { return ag_q16u_scale(t < 4 ? (int)((ex.x >> (8 * t)) & 0xffu) : (int)(ex.y & 0xffu)); }
+__device__ __forceinline__ void agg_q16_decode8(const int4 &w, float sc, float (&x)[8]) { ag_q16u_decode8(w, sc, x); }
+__device__ __forceinline__ void agg_q16_tile(const AggRowQ16 &r, int t, int h, f32x16 &v)
+{
+    const float sc = agg_q16_tile_scale(r.ex, t);
+    float lo[8], hi[8];
+    agg_q16_decode8(r.v[t][0], sc, lo);
+    agg_q16_decode8(r.v[t][1], sc, hi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = lo[k]; v[8 + k] = hi[k]; }
+    if (t == 4) {      // features 150..159 do not exist: their positions hold the exponent bytes (and zeros)
+        if (h) { v[10] = 0.0f; v[11] = 0.0f; }
+        v[12] = 0.0f; v[13] = 0.0f; v[14] = 0.0f; v[15] = 0.0f;
+    }
+}
 
 #define AG_LDS_DECL __shared__ __attribute__((aligned(16))) float lds[2 * AG_CHUNK_FLOATS]; __shared__ int s_next_tile[2];
 
@@ -1611,7 +1638,7 @@ __global__ __launch_bounds__(512, 1) void edge_encode_ws_kernel(AgWeights w, AgF
 // graph-steps/s), so this is ag_set_option("fuse_aggregate", 2), not the default.  Keeping 8 edges or three nodes per lane in
 // flight changed nothing (0.473 / 0.475 ms): the round is bandwidth-bound at what this access mix reaches, not latency-bound.
 #define AG_STAGE_LD 164
-template <class Prec, bool LAST, bool FUSE, bool HSQ = false>      // HSQ: the next round's sender table is written as q16 rows (mode 2)
+template <class Prec, bool LAST, bool FUSE, bool HSQ = false, bool AQ = false>      // HSQ: the next round's sender table is written as q16 rows (mode 2); AQ: `agg` is read as q16 rows
 __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_kernel(AgWeights w, AgFwdArgs a)
 {
     AG_LDS_DECL
@@ -1629,7 +1656,9 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
     }
     const bool ovf = a.ovf && *a.ovf != 0;      // de-duplicated call that overflowed the compact tables: Pn / h come from the packed tables
     const float *pn_rows = ovf ? nullptr : a.pn_rows, *h_rows = ovf ? nullptr : a.h_rows;
-    f32x16 agg_next[AG_NT];      // (!FUSE) the agg rows of the row tile about to start
+    f32x16 agg_next[AQ ? 1 : AG_NT];      // (!FUSE) the agg rows of the row tile about to start
+    AggRowQ16 aggq_next;                  // (AQ: as loaded, decoded where the operand image is built)
+    const unsigned char *aggq = reinterpret_cast<const unsigned char *>(a.agg);
     bool have_next = false;
 #pragma unroll 1
     while (q.tile < ntiles) {
@@ -1663,6 +1692,7 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                                 else ag_reduce_node_q16<AG_AGG_IN_FLIGHT, false, false>(ar, gn, c, ng * AG_AGG_GROUP, acc0, acc1);
                             }
                         }
+                        if (a.agg_q16) ag_q16_roundtrip_segment(acc0, acc1);      // (the 16-bit rounding the `agg` rows of the separate kernels go through: same bits)
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0) = acc0;
                         *reinterpret_cast<float4 *>(stage + r * AG_STAGE_LD + f0 + 8) = acc1;
                     }
@@ -1684,7 +1714,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
             }
         } else {
             // this row tile's agg rows: loaded during the PREVIOUS row tile's last two layers (below), except for a workgroup's first tile
-            if (!have_next) load_rowmajor(a.agg + (size_t)gc * AG_FP, agg_next, h);
+            if (!have_next) {
+                if constexpr (AQ) load_rowmajor_q16(aggq + (size_t)gc * (2 * AG_FP), aggq_next, h);
+                else load_rowmajor(a.agg + (size_t)gc * AG_FP, agg_next, h);
+            }
         }
         const size_t blk = (size_t)(tile * AG_MLP_WAVES + wave) * AG_PACK_BLOCK + h * 128 + j * 4;
         const size_t rowoff = (size_t)g * AG_FP + 4 * h;   // own row even when past Mn (padding rows)
@@ -1694,7 +1727,10 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
         resid.prefetch();      // issued before the operand split of agg below, whose ~250 VALU instructions cover part of the latency
         if constexpr (!FUSE) {
 #pragma unroll
-            for (int t = 0; t < AG_NT; ++t) Prec::set_tile(x, t, agg_next[t]);
+            for (int t = 0; t < AG_NT; ++t) {
+                if constexpr (AQ) { f32x16 v; agg_q16_tile(aggq_next, t, h, v); Prec::set_tile(x, t, v); }
+                else Prec::set_tile(x, t, agg_next[t]);
+            }
         }
         // The next row tile of this workgroup (static grid stride: TileQueue without a counter): its agg rows are fetched while this tile's second
         // and third layers run, into the registers the first layer's input image has just left.
@@ -1704,12 +1740,19 @@ __global__ __launch_bounds__(AG_MLP_THREADS, AG_MLP_WG_PER_CU) void node_update_
                 have_next = tile_n < ntiles;       // workgroup-uniform
                 if (have_next) {
                     const int gn = tile_n * AG_ROWS_PER_BLOCK + wave * 32 + j;
-                    load_rowmajor(a.agg + (size_t)(gn < Mn ? gn : 0) * AG_FP, agg_next, h);
+                    if constexpr (AQ) load_rowmajor_q16(aggq + (size_t)(gn < Mn ? gn : 0) * (2 * AG_FP), aggq_next, h);
+                    else load_rowmajor(a.agg + (size_t)(gn < Mn ? gn : 0) * AG_FP, agg_next, h);
                 } else {      // (a defined value on this path too: otherwise the previous tile's rows stay live through the whole first layer)
+                    if constexpr (AQ) {
 #pragma unroll
-                    for (int t = 0; t < AG_NT; ++t)
+                        for (int t = 0; t < AG_NT; ++t) { aggq_next.v[t][0] = make_int4(0, 0, 0, 0); aggq_next.v[t][1] = make_int4(0, 0, 0, 0); }
+                        aggq_next.ex = make_uint2(0u, 0u);
+                    } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) agg_next[t][r] = 0.0f;
+                        for (int t = 0; t < AG_NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) agg_next[t][r] = 0.0f;
+                    }
                 }
             }
         };
@@ -1839,7 +1882,7 @@ __device__ __forceinline__ void nws_write_half(unsigned char *set_lane, int step
     *reinterpret_cast<u32x4 *>(set_lane + (2 * step + 1) * 1024) = L;
 }
 
-template <int WAVE, bool HSQ>
+template <int WAVE, bool HSQ, bool AQ>
 __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a, unsigned char *sX, unsigned char *sY)
 {
     constexpr int N1 = WAVE == 3 ? 2 : 1, N2 = WAVE == 1 ? 2 : 1, N3 = WAVE == 2 ? 2 : 1;      // the fifth out-tiles: layer 1's to wave 3, Hr's to wave 1, Hs's to wave 2
@@ -1863,23 +1906,46 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
     auto gblock = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
     // input staging: this wave converts k16-steps WAVE, WAVE + 4, WAVE + 8 (< 10) of the next block's agg rows
     constexpr int NS = WAVE < 2 ? 3 : 2;
-    float4 raw[NS][2];
+    float4 raw[AQ ? 1 : NS][2];
+    int4 rawq[AQ ? NS : 1];      // AQ (`agg` as q16 rows): k16-step u of lane (j, h) is the 16 bytes at 64 (u >> 1) + 32 h + 16 (u & 1) of row j
+    uint2 rawex;
     auto stage_load = [&](int i) {
         const size_t g0 = (size_t)(i < n_i ? gblock(i) : 0) * 32 + j;
         const size_t g = g0 < (size_t)Mn ? g0 : 0;       // rows past B*N (last block): the reduce never wrote them — node 0's row instead of stale workspace bytes
-        const float *row = a.agg + g * AG_FP + 4 * h;
+        if constexpr (AQ) {
+            const unsigned char *rowb = reinterpret_cast<const unsigned char *>(a.agg) + g * (2 * AG_FP);
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int u = WAVE + 4 * k;
-            raw[k][0] = *reinterpret_cast<const float4 *>(row + 16 * u);
-            raw[k][1] = *reinterpret_cast<const float4 *>(row + 16 * u + 8);
+            for (int k = 0; k < NS; ++k) {
+                const int u = WAVE + 4 * k;
+                rawq[k] = *reinterpret_cast<const int4 *>(rowb + 64 * (u >> 1) + 32 * h + 16 * (u & 1));
+            }
+            rawex = *reinterpret_cast<const uint2 *>(rowb + 280);
+        } else {
+            const float *row = a.agg + g * AG_FP + 4 * h;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int u = WAVE + 4 * k;
+                raw[k][0] = *reinterpret_cast<const float4 *>(row + 16 * u);
+                raw[k][1] = *reinterpret_cast<const float4 *>(row + 16 * u + 8);
+            }
         }
     };
     auto stage_write = [&](unsigned char *set) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const float x[8] = {raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w};
-            nws_write_half(set + lane * 16, WAVE + 4 * k, x);
+            if constexpr (AQ) {
+                const int u = WAVE + 4 * k;
+                float x[8];
+                agg_q16_decode8(rawq[k], agg_q16_tile_scale(rawex, u >> 1), x);
+                if (u == 9) {      // features 150..159 do not exist (their positions hold the exponent bytes): h = 0 owns 144..147 | 152..155, h = 1 148..151 | 156..159
+                    if (h) { x[2] = 0.0f; x[3] = 0.0f; }
+                    x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
+                }
+                nws_write_half(set + lane * 16, u, x);
+            } else {
+                const float x[8] = {raw[k][0].x, raw[k][0].y, raw[k][0].z, raw[k][0].w, raw[k][1].x, raw[k][1].y, raw[k][1].z, raw[k][1].w};
+                nws_write_half(set + lane * 16, WAVE + 4 * k, x);
+            }
         }
     };
     // residual Pn + h of this wave's first-layer tiles, loaded one phase ahead; the compact-row index of a block (node de-duplication) one
@@ -1980,15 +2046,15 @@ __device__ __forceinline__ void nws_wave(const AgWeights &w, const AgFwdArgs &a,
     }
 }
 
-template <bool HSQ>
+template <bool HSQ, bool AQ>
 __global__ __launch_bounds__(256, 1) void node_update_nws_kernel(AgWeights w, AgFwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char sX[2 * AG_NWS_SET], sY[2 * AG_NWS_SET];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) nws_wave<0, HSQ>(w, a, sX, sY);
-    else if (wave == 1) nws_wave<1, HSQ>(w, a, sX, sY);
-    else if (wave == 2) nws_wave<2, HSQ>(w, a, sX, sY);
-    else nws_wave<3, HSQ>(w, a, sX, sY);
+    if (wave == 0) nws_wave<0, HSQ, AQ>(w, a, sX, sY);
+    else if (wave == 1) nws_wave<1, HSQ, AQ>(w, a, sX, sY);
+    else if (wave == 2) nws_wave<2, HSQ, AQ>(w, a, sX, sY);
+    else nws_wave<3, HSQ, AQ>(w, a, sX, sY);
 }
 
 // =====================================================================================================
@@ -2251,8 +2317,11 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
     if (a.precision == AG_PREC_B3 && !last && a.node_ws && !a.fuse_agg) {      // weight-stationary kernel: one workgroup per CU
         const int cus = a.max_blocks / AG_MLP_WG_PER_CU > 0 ? a.max_blocks / AG_MLP_WG_PER_CU : 1, nblk = (a.B * a.N + 31) / 32;
         const dim3 g2(nblk < cus ? nblk : cus);
-        if (a.hs_out_q16) hipLaunchKernelGGL(node_update_nws_kernel<true>, g2, dim3(256), 0, s, w, a);
-        else hipLaunchKernelGGL(node_update_nws_kernel<false>, g2, dim3(256), 0, s, w, a);
+        if (a.agg_q16) {
+            if (a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, true>), g2, dim3(256), 0, s, w, a);
+            else hipLaunchKernelGGL((node_update_nws_kernel<false, true>), g2, dim3(256), 0, s, w, a);
+        } else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, false>), g2, dim3(256), 0, s, w, a);
+        else hipLaunchKernelGGL((node_update_nws_kernel<false, false>), g2, dim3(256), 0, s, w, a);
         return;
     }
     if (a.precision == AG_PREC_B3) {
@@ -2260,6 +2329,10 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
             if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, true>), grid, block, 0, s, w, a);
             else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true, true>), grid, block, 0, s, w, a);
             else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true>), grid, block, 0, s, w, a);
+        } else if (a.agg_q16) {      // (mode 2 only: `agg` arrives as q16 rows)
+            if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false, false, true>), grid, block, 0, s, w, a);
+            else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true, true>), grid, block, 0, s, w, a);
+            else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, false, true>), grid, block, 0, s, w, a);
         } else if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false>), grid, block, 0, s, w, a);
         else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true>), grid, block, 0, s, w, a);
         else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false>), grid, block, 0, s, w, a);

@@ -138,10 +138,20 @@ class DynamicsPredictor(nn.Module):
         table ("fast", the default; its fp16 activations have fp16's range, see take_status); "rollout_streams"; "node_dedup";
         "fuse_aggregate"; "max_blocks"; "edge_products"; "edge_stationary"; "node_stationary"; "cu_split"; "self_edges" (r06: self-loops of the
         attribute classes (1, 0) / (0, 1) as one table row per class, default 1); "shared_state" (r06: rollouts of one cloud under many sampled
-        pushes compute per sample only what can differ from the tool-less base trajectory, default 0).  All of them give the same bits."""
+        pushes compute per sample only what can differ from the tool-less base trajectory, default 0).  All of them give the same bits, except
+        "precision" and "agg_q16" (r06, default 0: the per-node sums of a round travel as 16-bit block-scaled rows between the segment reduce and
+        node_update in mode 2 — one more rounding per node and round)."""
         dev = torch.device(device if device is not None else self.device)
         _lib.check(_lib.lib().ag_set_option(self.handle(dev), name.encode(), int(value)), f"ag_set_option({name})")
         return self
+
+    def get_option(self, name, device=None):
+        """The engine's CURRENT value of an option (ag_get_option: default, environment or set_option)."""
+        import ctypes
+        dev = torch.device(device if device is not None else self.device)
+        v = ctypes.c_int(0)
+        _lib.check(_lib.lib().ag_get_option(self.handle(dev), name.encode(), ctypes.byref(v)), f"ag_get_option({name})")
+        return v.value
 
     def __del__(self):
         try:

@@ -77,14 +77,14 @@ DTYPE = {"f32": "f32 (exact fp32 MFMA)",
          "bf16x3": "f32 operands split hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate",
          "fast": "node stacks: f32 operands split hi+lo bf16, 3 bf16 MFMAs per product; edge stack: f16(W) x f16(x) on the f16 MFMA + "
                  "[e4m3(W_lo) | e4m3(W_hi)] x [e5m2(x) | e5m2(x - f16(x))] on the block-scaled fp8 MFMA (W and x to ~2^-15); f32 accumulate; "
-                 "per-edge table 16-bit block-scaled fixed point (q16)"}
+                 "per-edge table, the senders' node terms and the per-node message sums 16-bit block-scaled fixed point (q16)"}
 # fp16-MFMA-times issued per fp32 product in the edge stack: split-bf16 3; "fast": ten f16 MFMAs + five scaled fp8 MFMAs (K = 64, 1.25 f16-MFMA-times
 # each under the power limit, tools/ubench/mx_mfma.hip) per 160 x 32 out-tile = 16.25 / 10
 EDGE_PRODUCTS = {"f32": 1, "bf16x3": 3, "fast": 1.625}
 DTYPE_TOKEN = {"f32": "f32", "bf16x3": "bf16x3", "fast": "f16+fp8corr+bf16x3"}
 # <= 100 characters: the driver's record truncates longer config strings (the full description is the line's top-level "arithmetic")
 ARITH_SHORT = {"f32": "exact fp32 MFMA", "bf16x3": "fp32 as hi+lo bf16, 3 MFMAs per product, f32 accumulate",
-               "fast": "edge: f16 MFMA + scaled-fp8 corrections; node: bf16x3; Eterm q16; f32 accumulate"}
+               "fast": "edge: f16 MFMA + scaled-fp8 corrections; node: bf16x3; Eterm/Hs/agg q16; f32 accumulate"}
 assert all(len(v) <= 100 for v in ARITH_SHORT.values())
 WORKLOADS = {"rope": dict(n_obj=1000, kw=dict(spacing=0.1)), "granular": dict(n_obj=2000, kw={}),
              "cloth": dict(n_obj=4096, kw={})}
@@ -342,8 +342,10 @@ class Engine:
                 # node tables per launch: Hr read + Hs first-touch + agg write = 3 x 640 B per node; with the node encoder de-duplicated
                 # (default) round 0 reads Hr / Hs from a few compact rows, so the three rounds average (1 + 3 + 3) / 3 tables.  In the default
                 # mode the rounds after the first gather Hs from q16 rows (320 B per node): 2.5 tables there
-                later = 2.5 if precision == "fast" else 3.0
-                tables = (3.0 + 2 * later) / 3.0 if self.get("node_dedup") == 0 else (1.0 + 2 * later) / 3.0
+                # (r06, option agg_q16, the default mode's default: `agg` leaves as q16 rows too: 320 B per node)
+                aggw = 0.5 if (precision == "fast" and self.get("agg_q16")) else 1.0
+                later = 1.5 + aggw if precision == "fast" else 3.0
+                tables = (2.0 + aggw + 2 * later) / 3.0 if self.get("node_dedup") == 0 else (aggw + 2 * later) / 3.0
                 nbytes = e_per * (320 if precision == "fast" else 640) + n_nodes * tables * 640
                 a_s = ms[ka] / cnt[ka] * 1e-3
                 t2, src2 = pmc_traffic(self.material, batch, precision, "aggregate")
@@ -565,7 +567,8 @@ def main():
                        "model_status": r["model_status"],
                        # engine options the timed region ran with (ag_get_option): self-loops as one table row per attribute class (exact, r06);
                        # shared_state 0 = every sample computed in full (the option's numbers are the separate shared_state_* / mpc_ms keys)
-                       "self_edges": -1 if args.dry_run else eng.get("self_edges"), "shared_state": -1 if args.dry_run else eng.get("shared_state")},
+                       "self_edges": -1 if args.dry_run else eng.get("self_edges"), "shared_state": -1 if args.dry_run else eng.get("shared_state"),
+                       "agg_q16": -1 if args.dry_run else eng.get("agg_q16")},
             "arithmetic": DTYPE[args.precision],
             "roofline": r["roofline"], "roofline_hbm": r["roofline_hbm"], "kernels": r["kernels"],
         }

@@ -91,6 +91,10 @@ int ag_model_destroy(ag_model *m);
  *                            private); one stream, node de-duplication forced on, workspace of ag_rollout_workspace_bytes_for(model, ...) with the option
  *                            set.  0 (default) = every sample in full — what the headline benchmark is quoted on.  Not combined with
  *                            "fuse_aggregate" 2 / "cu_split" (those calls take the plain path)
+ *   "agg_q16"          0/1   precision 2 with the defaults of "fuse_aggregate" / "node_stationary": 1 = the per-node sums of a propagation round (`agg`,
+ *                            model.py:295) travel from the segment reduce to node_update as 16-bit block-scaled rows (the per-edge table's format, 320 B
+ *                            instead of 640 B per node and round).  One more rounding per node and round: NOT bit-identical to 0 (default) — measured
+ *                            deviation and gain in docs/NEGATIVE_RESULTS.md R6.4; ignored where a kernel of the round does not read the format
  *   "cu_split"         0|8k  CU-partitioned rollout (off by default): the first `cu_split` CU-mask bits (cu_split / 8 CUs of every XCD) run the
  *                            MFMA-bound edge encoder, the other CUs the HBM-bound edge build / segment reduce / node update / state step, the batch
  *                            parts pipelined through the two partitions on two CU-masked queues (hipExtStreamCreateWithCUMask).  Bit-identical

@@ -516,6 +516,74 @@ def test_self_edge_elision_keeps_other_attribute_pairs_and_duplicate_particles(w
     assert m.take_status() == 0
 
 
+@pytest.mark.parametrize("name", golden_files("fwd_"))
+def test_agg_q16_option_holds_the_goldens(name, weights):
+    """ag_set_option("agg_q16", 1) (r06; the default of precision mode 2): the segment reduce stores `agg` as q16 rows (the per-edge table's row layout: 320 B,
+    one power-of-two scale per 32 features; unsigned values — the sums are >= 0: ag_q16_encode_segment) and node_update decodes them — one more 16-bit
+    rounding per node and round, half the bytes of that table.  Every forward golden stays inside the mode's tolerance with status 0 with the option on
+    and off; the streaming node_update and the reduce fused into node_update apply the same rounding (same bits); the other modes ignore the option."""
+    g = load_golden(name)
+    material = str(g["material"])
+    N = g["attrs"].shape[1]
+    csr = csr_from_lists(g["n_rel"], g["recv"], g["send"], N)
+    kw = {material + "_physics_param": t(g["phys"])}
+    scale = max(1.0, float(np.abs(g["pred_motion"]).max()))
+    m = make_model(weights_for(g, weights), material, float(g["decoder_scale"]), "fast")
+    args = (t(g["state"]), t(g["attrs"]), csr, None, t(g["p_instance"]))
+    assert m.get_option("agg_q16") == 1
+    _, mot = m(*args, action=t(g["action"]), **kw)
+    mot = mot.clone()
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC["fast"] * scale
+    for name_, val in (("node_stationary", 0), ("fuse_aggregate", 2)):
+        m.set_option(name_, val)
+        _, mot1 = m(*args, action=t(g["action"]), **kw)
+        assert torch.equal(mot1, mot), name_
+    m.set_option("node_stationary", 1).set_option("fuse_aggregate", 0)
+    m.set_option("agg_q16", 0)
+    _, mot0 = m(*args, action=t(g["action"]), **kw)
+    assert not torch.equal(mot, mot0)                  # the option is live
+    assert np.abs(mot0.cpu().numpy() - g["pred_motion"]).max() <= TOL_BY_PREC["fast"] * scale
+    assert m.take_status() == 0
+    m2 = make_model(weights_for(g, weights), material, float(g["decoder_scale"]), "bf16x3")
+    _, ref = m2(*args, action=t(g["action"]), **kw)
+    ref = ref.clone()
+    m2.set_option("agg_q16", 0)
+    _, got = m2(*args, action=t(g["action"]), **kw)
+    assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("material,n_obj,batch,steps", [("rope", 1000, 48, 5), ("rope", 333, 7, 4), ("cloth", 1024, 9, 3), ("granular", 2000, 6, 3)])
+def test_agg_q16_rollouts_keep_their_bitwise_equalities(weights, material, n_obj, batch, steps):
+    """With `agg` as q16 rows the sums the reduce forms are unchanged and their encoding is a function of the sum alone: self-edge elision, node
+    de-duplication, the shared-state rollout and a rollout alone vs inside a batch still agree bit for bit (row counts that are not a multiple of 32, an
+    scratch workspace full of 0xFF bytes), and the rollout stays within 10x the one-step tolerance of the default arithmetic after `steps` steps."""
+    m = make_model(weights, material, prec="fast")
+    kw = dict(spacing=0.1) if material == "rope" else {}
+    state, act = synth.make_mpc_inputs(material, n_obj, batch, n_look=1, seed=29, len_lo=steps, len_hi=steps + 0.9, **kw)
+
+    def run(sl=slice(None)):
+        return dynamics(t(state), t(act[sl]), m, DEV, _ppm(material))["state_seqs"].clone()
+
+    m.set_option("agg_q16", 0)
+    base = run()
+    m.set_option("agg_q16", 1)
+    ref = run()
+    torch.cuda.synchronize()
+    for buf in aggraph._WS.values():
+        buf.fill_(0xFF)
+    assert torch.isfinite(ref).all() and torch.equal(ref, run())
+    # (a rollout re-builds its edges from its own predictions: a top-k near-tie resolved the other way moves a few particles by more — the drift every
+    # arithmetic mode shows against the reference, profiles/r06_rollout_drift.txt — so the bound is on all but 1 % of the coordinates)
+    assert ((ref - base).abs() > 10 * TOL_BY_PREC["fast"]).float().mean().item() < 0.01
+    assert torch.equal(ref[:3], run(slice(0, 3)))
+    for name, val, back in [("self_edges", 0, 1), ("node_dedup", 0, 1), ("shared_state", 1, 0), ("rollout_streams", 2, 0), ("node_stationary", 0, 1),
+                            ("fuse_aggregate", 2, 0)]:
+        m.set_option(name, val)
+        assert torch.equal(ref, run()), name
+        m.set_option(name, back)
+    assert m.take_status() == 0
+
+
 @pytest.mark.parametrize("mode,material,n_obj,batch,steps", [
     ("fast", "rope", 1000, 96, 6), ("bf16x3", "rope", 1000, 40, 4), ("f32", "rope", 300, 33, 5), ("fast", "granular", 2000, 12, 3),
     ("fast", "cloth", 1024, 9, 4), ("fast", "rope", 100, 7, 4)])
@@ -1038,11 +1106,11 @@ def test_get_option_reports_what_the_engine_runs_with(weights):
         _lib.check(L.ag_get_option(h, name.encode(), ctypes.byref(v)), name)
         return v.value
 
-    assert (get("precision"), get("self_edges"), get("shared_state"), get("node_dedup"), get("rollout_streams"), get("fuse_aggregate")) == (2, 1, 0, 1, 0, 0)
+    assert (get("precision"), get("self_edges"), get("shared_state"), get("node_dedup"), get("rollout_streams"), get("fuse_aggregate"), get("agg_q16")) == (2, 1, 0, 1, 0, 0, 1)
     for name, val in (("precision", 1), ("precision", 0), ("self_edges", 0), ("shared_state", 1), ("node_dedup", 2), ("rollout_streams", 3), ("edge_products", 3),
-                      ("edge_stationary", 0), ("node_stationary", 0), ("cu_split", 64), ("fuse_aggregate", 2)):
+                      ("edge_stationary", 0), ("node_stationary", 0), ("cu_split", 64), ("fuse_aggregate", 2), ("agg_q16", 0)):
         m.set_option(name, val)
-        assert get(name) == val, name
+        assert get(name) == val and m.get_option(name) == val, name
     v = ctypes.c_int()
     assert L.ag_get_option(h, b"no_such_option", ctypes.byref(v)) != 0 and b"unknown option" in L.ag_last_error()
 
