@@ -141,7 +141,12 @@ def cpu_baseline(weights, material, n_obj, kw, T=10, gpu_out=None):
            "sample": f"{material} n_obj={n_obj}: the first {bsz} of the timed workload's 256 action samples (one graph per host thread), the full "
                      f"{steps}-step rollout, once ({dt:.1f} s), OpenMP over graphs: {min(cores, bsz)} of {cores} host threads busy"}
     if gpu_out and steps == T:
-        res["drift"] = {k: float(np.abs(v[:bsz] - seq[:, 0]).max()) for k, v in gpu_out.items() if v is not None and v.shape[0] >= bsz}
+        dev = {k: np.abs(v[:bsz] - seq[:, 0]) for k, v in gpu_out.items() if v is not None and v.shape[0] >= bsz}
+        res["drift"] = {k: float(d.max()) for k, d in dev.items()}
+        # the maximum is ONE coordinate: a near-tie that parts two trajectories moves a few particles by 1e-3 .. 1e-2 whatever the arithmetic (the exact-fp32
+        # mode shows the same); the median and the share of coordinates beyond the one-step gate say how the rest of the rollout compares
+        res["drift_median"] = {k: float(np.median(d)) for k, d in dev.items()}
+        res["drift_frac_over_1e-4"] = {k: float((d > 1e-4).mean()) for k, d in dev.items()}
         res["drift_note"] = (f"max |engine - oracle| of the predicted positions after the {T}-step rollout over those {bsz} samples; one-step deviation on "
                              "identical graphs is <= 1e-5 (gate 1e-4, tests/test_gpu_parity.py): larger values are top-k near-ties resolved differently")
     return res
@@ -598,7 +603,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(weights, args.material, wl["n_obj"], wl["kw"], T, gpu_out if want_drift else None)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             for mode, d in line["cpu_baseline"].get("drift", {}).items():      # flat keys the driver's record keeps (VERDICT r05 weak #1a)
-                line["config"][f"{'fast' if mode == 'fast' else mode}_drift"] = float(f"{d:.3g}")
+                line["config"][f"{mode}_drift"] = float(f"{d:.3g}")
+            for mode, d in line["cpu_baseline"].get("drift_frac_over_1e-4", {}).items():
+                line["config"][f"{mode}_drift_frac_over_gate"] = float(f"{d:.3g}")
             try:        # second baseline object: the reference's dense formulation (slower than the sparse port above, so the headline ratio stays conservative)
                 with leg("cpu_dense"):
                     line["cpu_baseline_dense_bmm"] = cpu_baseline_dense(weights, args.material, wl["n_obj"], wl["kw"])

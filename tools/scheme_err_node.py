@@ -7,7 +7,8 @@ Result (74 cases, seed 11; worst max-abs deviation of the predicted motion from 
     + receiver table Hr as q16 rows too                           1.5e-5        (Hr is common to all edges of a receiver: its error adds coherently)
     + Hs as plain fp16                                            1.9e-5
     + agg as q16 rows                                             1.8e-5
-    propagator / decoder / all node layers on the H3 arithmetic   1.1e-5 / 1.6e-5 / 2.3e-5"""
+    propagator / decoder / all node layers on the H3 arithmetic   1.1e-5 / 1.6e-5 / 2.3e-5
+r06: + agg as UNSIGNED q16 rows (shipped) 9.8e-6; on top of it Hr as q16 rows 1.6e-5 (one scale per 32) / 1.45e-5 (per 8), as 24-bit rows 9.7e-6."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools')); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -16,6 +17,13 @@ import torch.nn.functional as F
 import scheme_err as S
 from scheme_err import *
 
+def q_int_blk(x, blk, bits=16):      # q_int_tile with one scale per `blk` values
+    Fdim = x.shape[-1]
+    b = F.pad(x, (0, 160 - Fdim)).reshape(*x.shape[:-1], 160 // blk, blk)
+    mx = b.abs().amax(-1, keepdim=True).clamp(min=1e-300)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) + 1)
+    q = torch.round(b / sc * (2 ** (bits - 1) - 1)) / (2 ** (bits - 1) - 1) * sc
+    return q.reshape(*x.shape[:-1], 160)[..., :Fdim]
 def lin_h3(x, w, b=None):
     xe = h16(x); wh = h16(w)
     x8 = trunc_e5m2(xe)
@@ -58,11 +66,14 @@ def forward2(W, g, n_rel, recv, send, sch, nlin, which):
             else:
                 hr_t, hs_t = L("hrhs")(hcur, wrp[:, 150:300]), L("hrhs")(hcur, wrp[:, 300:])
                 if "hr_q16" in which: hr_t = q_int_tile(hr_t)
+                if "hr_q16b8" in which: hr_t = q_int_blk(hr_t, 8)
+                if "hr_q24" in which: hr_t = q_int_tile(hr_t, 24)
                 if "hs_q16" in which: hs_t = q_int_tile(hs_t)
                 if "hs_f16" in which: hs_t = h16(hs_t)
             eff = F.relu(eterm + hr_t[r] + hs_t[s])
             agg = torch.zeros(N, 150, dtype=torch.float64).index_add_(0, r, eff)
             if "agg_q16" in which: agg = q_int_tile(agg)
+            if "agg_q16u" in which: agg = q_int_tile(agg, 17)      # unsigned 16 bits of a non-negative value = the magnitude bits of a signed 17-bit one
             hcur = F.relu(pn + L("prop")(agg, wpp[:, 150:]) + hcur)
         x = hcur[:n_p]
         x = F.relu(L("dec")(x, W["non_rigid_predictor.linear_0.weight"], W["non_rigid_predictor.linear_0.bias"]))
@@ -77,6 +88,9 @@ ALL = ("hrhs", "prop", "dec", "dec2")
 variants = [("shipped: node stacks split-bf16, fp32 tables", lin_b3, ALL),
             ("+ Hs q16 (shipped since r04)", lin_b3, ALL + ("hs_q16",)), ("+ Hs q16 + Hr q16", lin_b3, ALL + ("hs_q16", "hr_q16")),
             ("+ Hs fp16", lin_b3, ALL + ("hs_f16",)), ("+ Hs q16 + agg q16", lin_b3, ALL + ("hs_q16", "agg_q16")),
+            # r06 (profiles/r06_agg_q16.txt (4)): the shipped unsigned agg rows, and the receiver table on top of them
+            ("+ Hs q16 + agg q16 UNSIGNED (shipped r06)", lin_b3, ALL + ("hs_q16", "agg_q16u")), ("shipped r06 + Hr q16 (per 32)", lin_b3, ALL + ("hs_q16", "agg_q16u", "hr_q16")),
+            ("shipped r06 + Hr q16 (per 8)", lin_b3, ALL + ("hs_q16", "agg_q16u", "hr_q16b8")), ("shipped r06 + Hr q24", lin_b3, ALL + ("hs_q16", "agg_q16u", "hr_q24")),
             ("propagator on H3", lin_h3, ("prop",)), ("decoder layers 0, 1 on H3", lin_h3, ("dec",)), ("all node layers on H3", lin_h3, ALL)]
 worst = {v[0]: (0.0, "") for v in variants}
 n = 0
