@@ -2317,10 +2317,9 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
     if (a.precision == AG_PREC_B3 && !last && a.node_ws && !a.fuse_agg) {      // weight-stationary kernel: one workgroup per CU
         const int cus = a.max_blocks / AG_MLP_WG_PER_CU > 0 ? a.max_blocks / AG_MLP_WG_PER_CU : 1, nblk = (a.B * a.N + 31) / 32;
         const dim3 g2(nblk < cus ? nblk : cus);
-        if (a.agg_q16) {
-            if (a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, true>), g2, dim3(256), 0, s, w, a);
-            else hipLaunchKernelGGL((node_update_nws_kernel<false, true>), g2, dim3(256), 0, s, w, a);
-        } else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, false>), g2, dim3(256), 0, s, w, a);
+        // (agg_q16 is a mode-2 option and mode 2 writes the next round's sender table as q16 rows: the combination <false, true> does not exist)
+        if (a.agg_q16 && a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, true>), g2, dim3(256), 0, s, w, a);
+        else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_nws_kernel<true, false>), g2, dim3(256), 0, s, w, a);
         else hipLaunchKernelGGL((node_update_nws_kernel<false, false>), g2, dim3(256), 0, s, w, a);
         return;
     }
@@ -2329,10 +2328,9 @@ void ag_launch_node_update(const AgWeights &w, const AgFwdArgs &a, int last, hip
             if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, true>), grid, block, 0, s, w, a);
             else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true, true>), grid, block, 0, s, w, a);
             else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, true>), grid, block, 0, s, w, a);
-        } else if (a.agg_q16) {      // (mode 2 only: `agg` arrives as q16 rows)
+        } else if (a.agg_q16 && (last || a.hs_out_q16)) {      // (mode 2 only: `agg` arrives as q16 rows; its rounds before the last write Hs as q16 rows)
             if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false, false, true>), grid, block, 0, s, w, a);
-            else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true, true>), grid, block, 0, s, w, a);
-            else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, false, true>), grid, block, 0, s, w, a);
+            else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true, true>), grid, block, 0, s, w, a);
         } else if (last) hipLaunchKernelGGL((node_update_kernel<PrecB3, true, false>), grid, block, 0, s, w, a);
         else if (a.hs_out_q16) hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false, true>), grid, block, 0, s, w, a);
         else hipLaunchKernelGGL((node_update_kernel<PrecB3, false, false>), grid, block, 0, s, w, a);
