@@ -37,6 +37,19 @@ def test_dynamic_symbol_table_is_exactly_the_header():
     assert exported == declared_symbols()
 
 
+def test_every_engine_option_is_documented_in_the_header_and_readable():
+    """The option names ag_set_option accepts (csrc/ag_api.hip) are exactly the ones ag_get_option answers, and each is described in the header's option list
+    (a caller of the C ABI has nothing else to go by)."""
+    src = open(os.path.join(ROOT, "adaptigraph_amd", "csrc", "ag_api.hip")).read()
+    body = lambda fn: src[src.index(f"int {fn}("):src.index("return AG_OK;", src.index(f"int {fn}("))]
+    names = lambda fn: set(re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', body(fn)))
+    setters, getters = names("ag_set_option"), names("ag_get_option")
+    assert setters == getters and len(setters) >= 12
+    header = open(os.path.join(ROOT, "include", "adaptigraph_hip.h")).read()
+    for n in sorted(setters):
+        assert f'"{n}"' in header, f"option {n} is not described in include/adaptigraph_hip.h"
+
+
 def test_version_and_capacity_queries():
     L = _lib.lib()
     assert L.ag_version() >= 1
