@@ -147,6 +147,9 @@ def cpu_baseline(weights, material, n_obj, kw, T=10, gpu_out=None):
         # mode shows the same); the median and the share of coordinates beyond the one-step gate say how the rest of the rollout compares
         res["drift_median"] = {k: float(np.median(d)) for k, d in dev.items()}
         res["drift_frac_over_1e-4"] = {k: float((d > 1e-4).mean()) for k, d in dev.items()}
+        # engine against engine: where the default mode and the exact-fp32 mode take the same side of every near-tie, their trajectories stay together
+        if "f32" in dev and all(gpu_out.get(k) is not None for k in ("fast", "f32")):
+            res["drift_fast_vs_f32_engine"] = float(np.abs(gpu_out["fast"][:bsz] - gpu_out["f32"][:bsz]).max())
         res["drift_note"] = (f"max |engine - oracle| of the predicted positions after the {T}-step rollout over those {bsz} samples; one-step deviation on "
                              "identical graphs is <= 1e-5 (gate 1e-4, tests/test_gpu_parity.py): larger values are top-k near-ties resolved differently")
     return res
@@ -606,6 +609,8 @@ def main():
                 line["config"][f"{mode}_drift"] = float(f"{d:.3g}")
             for mode, d in line["cpu_baseline"].get("drift_frac_over_1e-4", {}).items():
                 line["config"][f"{mode}_drift_frac_over_gate"] = float(f"{d:.3g}")
+            if "drift_fast_vs_f32_engine" in line["cpu_baseline"]:
+                line["config"]["fast_vs_f32_engine_drift"] = float(f"{line['cpu_baseline']['drift_fast_vs_f32_engine']:.3g}")
             try:        # second baseline object: the reference's dense formulation (slower than the sparse port above, so the headline ratio stays conservative)
                 with leg("cpu_dense"):
                     line["cpu_baseline_dense_bmm"] = cpu_baseline_dense(weights, args.material, wl["n_obj"], wl["kw"])
