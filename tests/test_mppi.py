@@ -104,6 +104,20 @@ def test_chamfer_kernel_vs_oracle_sizes(B, N, M, batched):
 
 
 @pytest.mark.gpu
+def test_chamfer_at_the_lds_limit_with_odd_cloud_sizes():
+    """N + M = 12 800 points is the documented limit of ag_chamfer (both clouds resident in LDS); r06 keeps the clouds as structure-of-arrays planes padded to
+    an even number of points (+inf pad points, read as pairs): odd sizes at the limit, one point beyond it is refused with an error code, not a crash."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 2, (1, 6401, 3)).astype(np.float32)
+    y = rng.normal(0.3, 2, (1, 6399, 3)).astype(np.float32)
+    got = losses.chamfer(tg(x), tg(y)).cpu().numpy()
+    ref = ago.chamfer(x, y)
+    assert np.abs(got - ref).max() <= 5e-6 * max(1.0, float(np.abs(ref).max()))
+    with pytest.raises(RuntimeError, match="LDS-resident limit"):
+        losses.chamfer(tg(x), tg(np.concatenate([y, y[:, :1]], 1)))
+
+
+@pytest.mark.gpu
 def test_mppi_step_vs_oracle_chain(weights):
     """One planner update from given samples: engine rollout + HIP chamfer + penalties + softmax update, against the
     oracle's rollout -> cost -> update chain on the same samples (exact-fp32 engine mode: no top-k flips)."""
